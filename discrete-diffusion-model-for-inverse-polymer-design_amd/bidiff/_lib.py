@@ -1,0 +1,136 @@
+"""ctypes binding of libbidiff_hip.so (the C ABI declared in include/bidiff.h).
+
+The library is built in-tree (``make -C csrc`` or ``__graft_entry__.build()``) and loaded from
+``<package>/lib``. There is no CPU or PyTorch fallback: if the shared object is missing or a
+call returns an error code, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libbidiff_hip.so")
+
+_lib = None
+
+c_i64p = C.c_void_p
+VP = C.c_void_p
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [
+        ("ln1_g", VP), ("ln1_b", VP),
+        ("w_qkv", VP), ("b_qkv", VP),
+        ("w_o", VP), ("b_o", VP),
+        ("ln2_g", VP), ("ln2_b", VP),
+        ("w_fc1", VP), ("b_fc1", VP),
+        ("w_fc2", VP), ("b_fc2", VP),
+    ]
+
+
+class BackboneDesc(C.Structure):
+    _fields_ = [
+        ("d", C.c_int), ("n_layers", C.c_int), ("n_heads", C.c_int), ("ffn", C.c_int),
+        ("vocab", C.c_int), ("vocab_pad", C.c_int), ("max_pos", C.c_int), ("n_timesteps", C.c_int),
+        ("ln_eps", C.c_float),
+        ("tok_emb", VP), ("pos_emb", VP), ("time_emb", VP),
+        ("lnf_g", VP), ("lnf_b", VP),
+        ("w_out", VP),
+        ("layers", C.POINTER(LayerWeights)),
+    ]
+
+
+class StepArgs(C.Structure):
+    _fields_ = [
+        ("ids", VP), ("fixed", VP), ("attn", VP), ("keymask", VP), ("has_eos", VP),
+        ("logits", VP), ("hidden", VP), ("wout", VP), ("u_sel", VP), ("u_tok", VP),
+        ("ktable", VP), ("tok_flags", VP), ("contrib", VP), ("ring_slot", VP),
+        ("counted_ids", VP), ("bond_ids", VP), ("non_special", VP),
+        ("n_counted", C.c_int), ("n_bond", C.c_int), ("n_ns", C.c_int), ("R", C.c_int),
+        ("B", C.c_int), ("L", C.c_int), ("V", C.c_int), ("d", C.c_int),
+        ("mask_id", C.c_int), ("pad_id", C.c_int), ("bos_id", C.c_int), ("eos_id", C.c_int),
+        ("open_id", C.c_int), ("close_id", C.c_int), ("boost_id", C.c_int),
+        ("variant", C.c_int), ("use_constraints", C.c_int), ("t", C.c_int),
+        ("temperature", C.c_float),
+        ("seed", C.c_ulonglong),
+        ("seq_offset", C.c_longlong),
+    ]
+
+
+class FixArgs(C.Structure):
+    _fields_ = [
+        ("ids", VP), ("logits", VP), ("attn", VP), ("keymask", VP), ("has_eos", VP),
+        ("tok_flags", VP), ("ring_ids", VP),
+        ("excl", C.c_int * 8),
+        ("n_excl", C.c_int), ("R", C.c_int),
+        ("B", C.c_int), ("L", C.c_int), ("V", C.c_int),
+        ("mask_id", C.c_int), ("pad_id", C.c_int), ("bos_id", C.c_int), ("eos_id", C.c_int),
+        ("open_id", C.c_int), ("close_id", C.c_int),
+        ("count_id", C.c_int), ("target", C.c_int),
+        ("do_fix", C.c_int), ("smiles_syntax", C.c_int), ("natural_eos", C.c_int),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/bidiff.h declares
+SIGNATURES = {
+    "bd_version": (C.c_char_p, []),
+    "bd_last_error": (C.c_char_p, []),
+    "bd_device_available": (C.c_int, []),
+    "bd_embed": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP]),
+    "bd_layernorm": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_float, VP]),
+    "bd_gemm_bf16": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
+    "bd_attention_fwd": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
+    "bd_mask_to_bytes": (C.c_int, [VP, VP, C.c_longlong, VP]),
+    "bd_backbone_workspace_bytes": (C.c_longlong, [C.POINTER(BackboneDesc), C.c_int, C.c_int]),
+    "bd_backbone_forward": (C.c_int, [C.POINTER(BackboneDesc), VP, VP, VP, C.c_int, C.c_int, VP,
+                                      C.c_longlong, VP, VP, VP]),
+    "bd_corrupt": (C.c_int, [VP, VP, VP, VP, C.c_int, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int,
+                             C.c_int, C.c_int, C.c_ulonglong, C.c_longlong, VP]),
+    "bd_sample_step": (C.c_int, [C.POINTER(StepArgs), VP]),
+    "bd_sample_fixup": (C.c_int, [C.POINTER(FixArgs), VP]),
+    "bd_host_gumbel": (None, [VP, VP, C.c_longlong]),
+    "bd_host_philox": (None, [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]),
+    "bd_host_uniform_select": (C.c_float, [C.c_ulonglong, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "bd_host_uniform_token": (C.c_float, [C.c_ulonglong, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "bd_prof_enable": (C.c_int, [C.c_int]),
+    "bd_prof_read": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
+}
+
+
+def lib():
+    """Load (once) and return the shared library; raise if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"bidiff: {LIB_PATH} not found - build it with `make -C "
+                f"{os.path.join(os.path.dirname(_HERE), 'csrc')}` (there is no fallback path)")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().bd_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"bidiff {what} failed ({rc}): {msg}")
+
+
+def ptr(t):
+    """Device (or host) address of a tensor, or None."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_handle():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_device(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"bidiff {what}: tensors must live on a ROCm device (got {t.device}); "
+            "this package has no CPU execution path")

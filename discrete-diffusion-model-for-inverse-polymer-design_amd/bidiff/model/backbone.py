@@ -1,0 +1,297 @@
+"""Bidirectional pre-LN transformer denoiser, executed by the HIP library.
+
+Drop-in for the reference's ``src/model/backbone.py`` (``DiffusionBackbone``, :132-377):
+same constructor arguments, sub-module / parameter names (hence the same ``state_dict`` keys
+and checkpoint layout), the same seeded initialisation, and the same public methods. The
+modules below only *hold* parameters; all arithmetic runs in ``libbidiff_hip.so`` through
+``bd_backbone_forward`` (inference) or the training-step kernels (autograd path).
+"""
+import ctypes as C
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+
+class MultiHeadAttention(nn.Module):
+    """Parameter container: q/k/v/out projections (reference backbone.py:9-30)."""
+
+    def __init__(self, hidden_size: int, num_heads: int, dropout: float = 0.1):
+        super().__init__()
+        if hidden_size % num_heads != 0:
+            raise AssertionError("hidden_size must be divisible by num_heads")
+        self.hidden_size = hidden_size
+        self.num_heads = num_heads
+        self.head_dim = hidden_size // num_heads
+        self.q_proj = nn.Linear(hidden_size, hidden_size)
+        self.k_proj = nn.Linear(hidden_size, hidden_size)
+        self.v_proj = nn.Linear(hidden_size, hidden_size)
+        self.out_proj = nn.Linear(hidden_size, hidden_size)
+        self.dropout = nn.Dropout(dropout)
+
+
+class FeedForward(nn.Module):
+    """Parameter container: fc1 -> GELU -> fc2 (reference backbone.py:81-93)."""
+
+    def __init__(self, hidden_size: int, ffn_hidden_size: int, dropout: float = 0.1):
+        super().__init__()
+        self.fc1 = nn.Linear(hidden_size, ffn_hidden_size)
+        self.fc2 = nn.Linear(ffn_hidden_size, hidden_size)
+        self.dropout = nn.Dropout(dropout)
+
+
+class TransformerBlock(nn.Module):
+    """Parameter container of one pre-norm block (reference backbone.py:104-118)."""
+
+    def __init__(self, hidden_size: int, num_heads: int, ffn_hidden_size: int, dropout: float = 0.1):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(hidden_size)
+        self.attn = MultiHeadAttention(hidden_size, num_heads, dropout)
+        self.norm2 = nn.LayerNorm(hidden_size)
+        self.ffn = FeedForward(hidden_size, ffn_hidden_size, dropout)
+
+
+class _Packed:
+    """bf16 copies of the matrices + the C descriptor pointing at them."""
+
+    def __init__(self):
+        self.key = None
+        self.tensors = []
+        self.layers = None
+        self.desc = None
+        self.w_out = None
+
+
+class DiffusionBackbone(nn.Module):
+    """Transformer denoiser for discrete masking diffusion (reference backbone.py:132-377)."""
+
+    def __init__(
+        self,
+        vocab_size: int,
+        hidden_size: int = 768,
+        num_layers: int = 12,
+        num_heads: int = 12,
+        ffn_hidden_size: int = 3072,
+        max_position_embeddings: int = 256,
+        num_diffusion_steps: int = 100,
+        dropout: float = 0.1,
+        pad_token_id: int = 0,
+    ):
+        super().__init__()
+        self.vocab_size = vocab_size
+        self.hidden_size = hidden_size
+        self.num_layers = num_layers
+        self.num_heads = num_heads
+        self.ffn_hidden_size = ffn_hidden_size
+        self.max_position_embeddings = max_position_embeddings
+        self.num_diffusion_steps = num_diffusion_steps
+        self.dropout = dropout
+        self.pad_token_id = pad_token_id
+
+        self.token_embedding = nn.Embedding(vocab_size, hidden_size, padding_idx=pad_token_id)
+        self.position_embedding = nn.Embedding(max_position_embeddings, hidden_size)
+        self.timestep_embedding = nn.Embedding(num_diffusion_steps + 1, hidden_size)
+        self.embedding_dropout = nn.Dropout(dropout)
+        self.layers = nn.ModuleList(
+            [TransformerBlock(hidden_size, num_heads, ffn_hidden_size, dropout) for _ in range(num_layers)]
+        )
+        self.final_norm = nn.LayerNorm(hidden_size)
+        self.output_proj = nn.Linear(hidden_size, vocab_size, bias=False)
+        self._init_weights()
+        self._packed = _Packed()
+        self._ws = None
+
+    # ------------------------------------------------------------------ init
+    def _init_weights(self):
+        """Xavier-uniform matrices, zero biases, N(0, 0.02) embeddings with a zero pad row,
+        unit LayerNorms - visited in ``self.modules()`` order so that a given torch seed
+        produces the reference's weights (reference backbone.py:200-213)."""
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.Embedding):
+                nn.init.normal_(m.weight, mean=0.0, std=0.02)
+                if m.padding_idx is not None:
+                    nn.init.zeros_(m.weight[m.padding_idx])
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+
+    # ------------------------------------------------------------------ packing
+    def _pack_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def packed(self) -> _Packed:
+        """bf16 weight copies and the bd_backbone_desc; rebuilt when any parameter changed."""
+        key = self._pack_key()
+        pk = self._packed
+        if pk.key == key:
+            return pk
+        dev = self.output_proj.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("bidiff DiffusionBackbone: move the model to a ROCm device first "
+                               "(no CPU execution path)")
+        d, F, V = self.hidden_size, self.ffn_hidden_size, self.vocab_size
+        keep = []
+
+        def bf(w):
+            t = w.detach().to(torch.bfloat16).contiguous()
+            keep.append(t)
+            return t
+
+        def f32(w):
+            t = w.detach().to(torch.float32).contiguous()
+            keep.append(t)
+            return t
+
+        layers = (_lib.LayerWeights * max(1, self.num_layers))()
+        with torch.no_grad():
+            for i, blk in enumerate(self.layers):
+                a = blk.attn
+                wqkv = bf(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0))
+                bqkv = f32(torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], dim=0))
+                lw = layers[i]
+                lw.ln1_g = f32(blk.norm1.weight).data_ptr(); lw.ln1_b = f32(blk.norm1.bias).data_ptr()
+                lw.w_qkv = wqkv.data_ptr(); lw.b_qkv = bqkv.data_ptr()
+                lw.w_o = bf(a.out_proj.weight).data_ptr(); lw.b_o = f32(a.out_proj.bias).data_ptr()
+                lw.ln2_g = f32(blk.norm2.weight).data_ptr(); lw.ln2_b = f32(blk.norm2.bias).data_ptr()
+                lw.w_fc1 = bf(blk.ffn.fc1.weight).data_ptr(); lw.b_fc1 = f32(blk.ffn.fc1.bias).data_ptr()
+                lw.w_fc2 = bf(blk.ffn.fc2.weight).data_ptr(); lw.b_fc2 = f32(blk.ffn.fc2.bias).data_ptr()
+            vpad = ((V + 127) // 128) * 128
+            w_out = torch.zeros(vpad, d, dtype=torch.bfloat16, device=dev)
+            w_out[:V] = self.output_proj.weight.detach().to(torch.bfloat16)
+            keep.append(w_out)
+            desc = _lib.BackboneDesc()
+            desc.d, desc.n_layers, desc.n_heads, desc.ffn = d, self.num_layers, self.num_heads, F
+            desc.vocab, desc.vocab_pad = V, vpad
+            desc.max_pos, desc.n_timesteps = self.max_position_embeddings, self.num_diffusion_steps + 1
+            desc.ln_eps = float(self.final_norm.eps)
+            desc.tok_emb = f32(self.token_embedding.weight).data_ptr()
+            desc.pos_emb = f32(self.position_embedding.weight).data_ptr()
+            desc.time_emb = f32(self.timestep_embedding.weight).data_ptr()
+            desc.lnf_g = f32(self.final_norm.weight).data_ptr()
+            desc.lnf_b = f32(self.final_norm.bias).data_ptr()
+            desc.w_out = w_out.data_ptr()
+            desc.layers = C.cast(layers, C.POINTER(_lib.LayerWeights))
+        pk.key, pk.tensors, pk.layers, pk.desc, pk.w_out = key, keep, layers, desc, w_out
+        return pk
+
+    def _workspace(self, pk, B, L, device):
+        need = _lib.lib().bd_backbone_workspace_bytes(C.byref(pk.desc), B, L)
+        if need < 0:
+            _lib.check(-1, "bd_backbone_workspace_bytes")
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._ws, need
+
+    # ------------------------------------------------------------------ native forward
+    def _check_inputs(self, input_ids, timesteps):
+        _lib.require_device(input_ids, "DiffusionBackbone.forward")
+        if input_ids.dim() != 2:
+            raise ValueError("input_ids must be [batch, seq_len]")
+        if timesteps.dim() == 2:
+            timesteps = timesteps.squeeze(-1)
+        if timesteps.shape[0] != input_ids.shape[0]:
+            raise ValueError("timesteps must have one entry per sequence")
+        return timesteps.to(device=input_ids.device, dtype=torch.long).contiguous()
+
+    @staticmethod
+    def _keymask_bytes(attention_mask, like):
+        if attention_mask is None:
+            return None
+        if attention_mask.dtype == torch.uint8 and attention_mask.is_contiguous():
+            return attention_mask
+        return (attention_mask != 0).to(torch.uint8).contiguous()
+
+    def run_forward(self, input_ids, timesteps, keymask, want_hidden=True, want_logits=False,
+                    hidden_out=None, logits_out=None):
+        """One inference forward on the current stream. keymask: uint8 [B,L] or None.
+        Returns (hidden bf16 [B,L,d] or None, logits fp32 [B,L,V] or None)."""
+        timesteps = self._check_inputs(input_ids, timesteps)
+        ids = input_ids.to(torch.long).contiguous()
+        B, L = ids.shape
+        pk = self.packed()
+        ws, need = self._workspace(pk, B, L, ids.device)
+        if want_hidden and hidden_out is None:
+            hidden_out = torch.empty(B, L, self.hidden_size, dtype=torch.bfloat16, device=ids.device)
+        if want_logits and logits_out is None:
+            logits_out = torch.empty(B, L, self.vocab_size, dtype=torch.float32, device=ids.device)
+        rc = _lib.lib().bd_backbone_forward(
+            C.byref(pk.desc), _lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(keymask), B, L,
+            _lib.ptr(ws), need, _lib.ptr(hidden_out) if want_hidden else None,
+            _lib.ptr(logits_out) if want_logits else None, _lib.stream_handle())
+        _lib.check(rc, "bd_backbone_forward")
+        return (hidden_out if want_hidden else None), (logits_out if want_logits else None)
+
+    # ------------------------------------------------------------------ reference API
+    def forward(self, input_ids: torch.Tensor, timesteps: torch.Tensor,
+                attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Logits [batch, seq_len, vocab] (fp32, computed with bf16 MFMA GEMMs).
+
+        With autograd recording and parameters that require grad this runs the training
+        path (activations saved for the HIP backward kernels); otherwise the inference path.
+        """
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from ..training.autograd import backbone_forward_train
+            return backbone_forward_train(self, input_ids, timesteps, attention_mask)
+        keymask = self._keymask_bytes(attention_mask, input_ids)
+        _, logits = self.run_forward(input_ids, timesteps, keymask, want_hidden=False, want_logits=True)
+        return logits
+
+    def get_hidden_states(self, input_ids, timesteps, attention_mask=None, layer_idx: int = -1):
+        """Final-norm hidden states [batch, seq_len, hidden] (reference backbone.py:259-299).
+        Only ``layer_idx == -1`` (all layers + final norm) is executed natively."""
+        if layer_idx != -1:
+            raise NotImplementedError("bidiff: intermediate-layer hidden states are not built yet")
+        keymask = self._keymask_bytes(attention_mask, input_ids)
+        hidden, _ = self.run_forward(input_ids, timesteps, keymask, want_hidden=True, want_logits=False)
+        return hidden.float()
+
+    def get_pooled_output(self, input_ids, timesteps, attention_mask=None, pooling: str = "mean"):
+        """Masked mean / cls / max pooling of the final hidden states (reference :301-335)."""
+        hs = self.get_hidden_states(input_ids, timesteps, attention_mask)
+        if pooling == "mean":
+            if attention_mask is not None:
+                m = attention_mask.unsqueeze(-1).float()
+                return (hs * m).sum(dim=1) / m.sum(dim=1).clamp(min=1e-9)
+            return hs.mean(dim=1)
+        if pooling == "cls":
+            return hs[:, 0]
+        if pooling == "max":
+            if attention_mask is not None:
+                m = attention_mask.unsqueeze(-1).float()
+                hs = hs * m + (1 - m) * (-1e9)
+            return hs.max(dim=1)[0]
+        raise ValueError(f"Unknown pooling method: {pooling}")
+
+    def config_dict(self):
+        return {
+            "vocab_size": self.vocab_size,
+            "hidden_size": self.hidden_size,
+            "num_layers": self.num_layers,
+            "num_heads": self.num_heads,
+            "ffn_hidden_size": self.ffn_hidden_size,
+            "max_position_embeddings": self.max_position_embeddings,
+            "num_diffusion_steps": self.num_diffusion_steps,
+            "dropout": self.dropout,
+            "pad_token_id": self.pad_token_id,
+        }
+
+    def save_pretrained(self, path: str):
+        """{'state_dict', 'config'} checkpoint, the reference's layout (backbone.py:337-356)."""
+        torch.save({"state_dict": self.state_dict(), "config": self.config_dict()}, path)
+
+    @classmethod
+    def load_pretrained(cls, path: str, device: str = "cpu", **kwargs) -> "DiffusionBackbone":
+        """Load a save_pretrained checkpoint. Tensors only: the file is read with
+        ``weights_only=True`` (the reference passes False, backbone.py:370)."""
+        ckpt = torch.load(path, map_location=device, weights_only=True)
+        cfg = dict(ckpt["config"])
+        cfg.update(kwargs)
+        model = cls(**cfg)
+        model.load_state_dict(ckpt["state_dict"])
+        return model

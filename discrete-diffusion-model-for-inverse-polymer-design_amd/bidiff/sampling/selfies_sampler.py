@@ -1,0 +1,120 @@
+"""ConstrainedSampler for SELFIES token sequences.
+
+Drop-in for ``Bi_Diffusion_SELFIES/src/sampling/sampler.py``: the only chemistry constraint
+is "exactly two ``[I+3]`` placeholders" (forbid a third, boost the placeholder when few
+masked slots remain), chosen positions are drawn left to right, and EOS is either fixed at
+the last position (default) or sampled (``allow_natural_eos=True``).
+"""
+from collections import defaultdict
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import core
+from .sampler import _progress
+
+
+class ConstrainedSampler:
+    def __init__(self, diffusion_model, tokenizer, num_steps: int = 100, temperature: float = 1.0,
+                 use_constraints: bool = True, device: str = "cuda"):
+        self.diffusion_model = diffusion_model
+        self.tokenizer = tokenizer
+        self.num_steps = num_steps
+        self.temperature = temperature
+        self.use_constraints = use_constraints
+        self.device = device
+        if self.temperature <= 0:
+            raise ValueError(f"temperature must be > 0, got {self.temperature}")
+        self.mask_id = tokenizer.mask_token_id
+        self.pad_id = tokenizer.pad_token_id
+        self.bos_id = tokenizer.bos_token_id
+        self.eos_id = tokenizer.eos_token_id
+        self.placeholder_id = tokenizer.get_placeholder_token_id()
+        special = {self.mask_id, self.pad_id, self.bos_id, self.eos_id}
+        self.non_special_token_ids = [i for i in range(tokenizer.vocab_size) if i not in special]
+        if not self.non_special_token_ids:
+            self.non_special_token_ids = list(range(tokenizer.vocab_size))
+        self._core = core.ReverseSampler(diffusion_model, self._build_tables(), num_steps, temperature,
+                                         use_constraints, device)
+
+    def _build_tables(self) -> core.TokenTables:
+        V = int(self.diffusion_model.backbone.vocab_size)
+        flags = np.zeros(V, dtype=np.uint8)
+        for tok in (self.mask_id, self.pad_id, self.bos_id):
+            if 0 <= tok < V:
+                flags[tok] |= core.TF_SPECIAL
+        if 0 <= self.eos_id < V:
+            flags[self.eos_id] |= core.TF_EOS
+        contrib = np.zeros(V, dtype=np.int32)
+        contrib[self.placeholder_id] = 1
+        return core.TokenTables(
+            V=V, mask_id=int(self.mask_id), pad_id=int(self.pad_id), bos_id=int(self.bos_id),
+            eos_id=int(self.eos_id), boost_id=int(self.placeholder_id), count_id=int(self.placeholder_id),
+            variant=core.VB_URGENCY | core.VB_SORTED, tok_flags=flags, contrib=contrib,
+            non_special=list(self.non_special_token_ids),
+            fix_excl=[int(self.mask_id), int(self.pad_id)], fix_syntax=False).finish()
+
+    def sample(self, batch_size: int, seq_length: int, show_progress: bool = True,
+               allow_natural_eos: bool = False, seq_offset: int = 0) -> Tuple[torch.Tensor, List[str]]:
+        """All positions but BOS (and, by default, a fixed final EOS) start masked
+        (reference SELFIES sampler.py:243-419)."""
+        self.diffusion_model.eval()
+        ids = torch.full((batch_size, seq_length), self.mask_id, dtype=torch.long, device=self.device)
+        ids[:, 0] = self.bos_id
+        has_eos = torch.zeros(batch_size, dtype=torch.uint8, device=self.device)
+        if not allow_natural_eos:
+            ids[:, -1] = self.eos_id
+            has_eos[:] = 1
+        attention_mask = torch.ones_like(ids)
+        self._core.num_steps = int(self.num_steps)
+        self._core.temperature = float(self.temperature)
+        self._core.use_constraints = bool(self.use_constraints)
+        ids = self._core.run(ids, attention_mask, None, natural_eos=allow_natural_eos, seq_offset=seq_offset,
+                             progress=_progress(show_progress, "Sampling"), has_eos=has_eos)
+        strings = self.tokenizer.batch_decode(ids.cpu().tolist(), skip_special_tokens=True)
+        return ids, strings
+
+    def sample_batch(self, num_samples: int, seq_length: int, batch_size: int = 256,
+                     show_progress: bool = True, lengths: Optional[List[int]] = None):
+        """Fixed-length batches, or - given ``lengths`` - one group of batches per distinct
+        length with the strings returned in the caller's order (reference :421-502)."""
+        all_ids, all_strings = [], []
+        if lengths is None:
+            while len(all_strings) < num_samples:
+                cur = min(batch_size, num_samples - len(all_strings))
+                ids, s = self.sample(cur, seq_length, show_progress=False, seq_offset=len(all_strings))
+                all_ids.append(ids)
+                all_strings.extend(s)
+            return all_ids, all_strings
+        groups = defaultdict(list)
+        for i, ln in enumerate(lengths):
+            groups[ln].append(i)
+        result = [None] * len(lengths)
+        done = 0
+        for ln in sorted(groups):
+            idxs = groups[ln]
+            got = []
+            while len(got) < len(idxs):
+                cur = min(batch_size, len(idxs) - len(got))
+                ids, s = self.sample(cur, ln, show_progress=False, seq_offset=done)
+                all_ids.append(ids)
+                got.extend(s)
+                done += cur
+            for local, glob in enumerate(idxs):
+                result[glob] = got[local]
+        return all_ids, result
+
+    def sample_variable_length(self, num_samples: int, length_range: Tuple[int, int] = (20, 100),
+                               batch_size: int = 256, samples_per_length: int = 16,
+                               show_progress: bool = True):
+        lo, hi = length_range
+        inner = min(batch_size, samples_per_length)
+        all_ids, all_strings = [], []
+        while len(all_strings) < num_samples:
+            cur = min(inner, num_samples - len(all_strings))
+            ids, s = self.sample(cur, int(np.random.randint(lo, hi + 1)), show_progress=False,
+                                 seq_offset=len(all_strings))
+            all_ids.append(ids)
+            all_strings.extend(s)
+        return all_ids, all_strings

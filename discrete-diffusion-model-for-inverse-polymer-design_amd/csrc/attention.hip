@@ -1,0 +1,223 @@
+// Fused non-causal self-attention with a key-padding mask (gfx950, bf16 MFMA).
+//
+// Input is the fused QKV projection output [B*L, 3*d] (row = q | k | v, head h at
+// columns h*DH .. h*DH+DH-1 of each third); output is [B*L, d] bf16 with heads merged.
+// Semantics follow torch SDPA with a boolean mask broadcast over queries: masked keys
+// get weight 0, and a query whose keys are ALL masked yields an all-zero output row
+// (never NaN).
+//
+// One workgroup = 4 waves = 64 queries of one (batch, head); each wave owns 16 queries.
+// Keys/values are staged 128 at a time into LDS (256-byte rows, XOR-swizzled 16-byte
+// chunks). Both products are computed transposed so that every softmax quantity is
+// lane-local:
+//   S^T = K Q^T      A = K rows from LDS (ds_read_b128), B = Q fragment in registers
+//   O^T = V^T P^T    A = V^T through the transposing LDS read, B = P^T straight from
+//                    the S^T accumulators (no LDS round trip, no shuffles)
+// The K rows fed to the first product are permuted inside each 32-key group so that the
+// accumulator registers of two adjacent 16-key tiles are exactly one k-step of the
+// second product in natural key order.
+#include "bd_common.h"
+
+namespace {
+
+constexpr int KT = 128;        // keys per LDS tile
+constexpr int ROWB = 256;      // LDS row stride in bytes (also for DH < 128)
+
+__device__ __forceinline__ int kv_off(int row, int ch) {
+  return ROWB * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+__device__ __forceinline__ s16x4 lds_read_tr(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(p));
+}
+
+template <int DH>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* __restrict__ qkv,
+                                                          const unsigned char* __restrict__ keymask,
+                                                          unsigned short* __restrict__ out,
+                                                          float* __restrict__ lse_out,
+                                                          int L, int H, float scale) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KT * ROWB + KT];
+  unsigned char* const Ks = smem;
+  unsigned char* const Vs = smem + KT * ROWB;
+  unsigned char* const Ms = smem + 2 * KT * ROWB;
+
+  constexpr int KS = DH / 32;   // k-steps of the first product
+  constexpr int DT = DH / 16;   // output d-tiles of the second product
+  constexpr int CPR = DH / 8;   // 16-byte chunks per K/V row
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int d = H * DH;
+  const size_t row3 = (size_t)3 * d;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+
+  // Q fragment: lane holds Q[q0 + c][32 ks + 8 g .. +7]
+  bf16x8 qf[KS];
+  {
+    int qr = q0 + c; qr = qr < L ? qr : L - 1;
+    const unsigned short* qp = qkv + ((size_t)b * L + qr) * row3 + (size_t)h * DH + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + 32 * ks);
+  }
+
+  f32x4 o[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  for (int kt0 = 0; kt0 < L; kt0 += KT) {
+    if (kt0 > 0) __syncthreads();
+    // ---- stage K, V (zero rows past L) and the key mask tile
+    for (int idx = tid; idx < KT * CPR; idx += 256) {
+      const int row = idx / CPR, ch = idx % CPR;
+      const int key = kt0 + row;
+      u32x4 kv = (u32x4){0u, 0u, 0u, 0u}, vv = (u32x4){0u, 0u, 0u, 0u};
+      if (key < L) {
+        const unsigned short* base = qkv + ((size_t)b * L + key) * row3 + (size_t)h * DH + ch * 8;
+        kv = *(const u32x4*)(base + d);
+        vv = *(const u32x4*)(base + 2 * d);
+      }
+      const int off = kv_off(row, ch);
+      *(u32x4*)(Ks + off) = kv;
+      *(u32x4*)(Vs + off) = vv;
+    }
+    if (tid < KT) {
+      const int key = kt0 + tid;
+      unsigned char mv = 0;
+      if (key < L) mv = keymask ? (keymask[(size_t)b * L + key] != 0) : 1;
+      Ms[tid] = mv;
+    }
+    __syncthreads();
+
+    // ---- S^T tiles: s[tile][r] <-> key_local = 32 (tile>>1) + 8 g + 4 (tile&1) + r, query c
+    f32x4 s[8];
+#pragma unroll
+    for (int tile = 0; tile < 8; ++tile) {
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int krow = 32 * (tile >> 1) + 8 * (c >> 2) + 4 * (tile & 1) + (c & 3);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 a = *(const bf16x8*)(Ks + kv_off(krow, 4 * ks + g));
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], acc, 0, 0, 0);
+      }
+      s[tile] = acc;
+    }
+
+    // ---- masked online softmax along keys (lane-local + the 4 lanes sharing c)
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int tile = 0; tile < 8; ++tile) {
+      const int kb = 32 * (tile >> 1) + 8 * g + 4 * (tile & 1);
+      const unsigned int m4 = *(const unsigned int*)(Ms + kb);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool vis = ((m4 >> (8 * r)) & 0xffu) != 0u;
+        const float v = vis ? s[tile][r] * scale : -INFINITY;
+        s[tile][r] = v;
+        mloc = fmaxf(mloc, v);
+      }
+    }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float m_new = fmaxf(m_run, mloc);
+    const bool dead = (m_new == -INFINITY);
+    const float m_use = dead ? 0.f : m_new;
+    const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_use);
+    float psum = 0.f;
+#pragma unroll
+    for (int tile = 0; tile < 8; ++tile)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = __expf(s[tile][r] - m_use);  // exp(-inf) = 0 for masked keys
+        s[tile][r] = pv;
+        psum += pv;
+      }
+    psum += __shfl_xor(psum, 16, 64);
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) {
+      o[i][0] *= alpha; o[i][1] *= alpha; o[i][2] *= alpha; o[i][3] *= alpha;
+    }
+
+    // ---- P^T fragments: k-step s4 covers keys 32 s4 + 8 g + j = tiles (2 s4, 2 s4 + 1)
+    bf16x8 pf[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      bf16x8 t;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        t[r] = (__bf16)s[2 * s4][r];
+        t[4 + r] = (__bf16)s[2 * s4 + 1][r];
+      }
+      pf[s4] = t;
+    }
+
+    // ---- O^T += V^T P^T ; V^T fragment via two transposing reads of 4 keys x 16 d
+    const int q4 = c >> 2, p4 = c & 3;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int r0 = 32 * s4 + 8 * g + q4;
+        const int ch = 2 * dt + (p4 >> 1);
+        const s16x4 lo = lds_read_tr(Vs + kv_off(r0, ch) + 8 * (p4 & 1));
+        const s16x4 hi = lds_read_tr(Vs + kv_off(r0 + 4, ch) + 8 * (p4 & 1));
+        union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+        u.s.a = lo; u.s.b = hi;
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pf[s4], o[dt], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- normalise and store: lane holds O[q0 + c][16 dt + 4 g + r]
+  const int qrow = q0 + c;
+  const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+  if (qrow < L) {
+    unsigned short* op = out + ((size_t)b * L + qrow) * d + (size_t)h * DH + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      u32x2 w;
+      w[0] = bd_pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv);
+      w[1] = bd_pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
+      *(u32x2*)(op + 16 * dt) = w;
+    }
+    if (lse_out != nullptr && g == 0)
+      lse_out[((size_t)b * H + h) * L + qrow] = l_run > 0.f ? (m_run + __logf(l_run)) : -INFINITY;
+  }
+}
+
+}  // namespace
+
+// qkv [B*L, 3*H*DH] bf16, keymask [B, L] bytes (non-zero = visible) or null,
+// out [B*L, H*DH] bf16, lse (optional) [B, H, L] fp32 log-sum-exp of the scaled scores.
+extern "C" int bd_attention_fwd(const void* qkv, const unsigned char* keymask, void* out,
+                                float* lse, int B, int L, int H, int head_dim, void* stream) {
+  BD_REQUIRE(qkv && out, "bd_attention_fwd: null operand");
+  BD_REQUIRE(B > 0 && L > 0 && H > 0, "bd_attention_fwd: empty shape");
+  BD_REQUIRE(B <= 65535 && H <= 65535, "bd_attention_fwd: B and H must be <= 65535");
+  const float scale = 1.0f / sqrtf((float)head_dim);
+  dim3 grid((L + 63) / 64, H, B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (head_dim) {
+    case 32:
+      hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, 0, s, (const unsigned short*)qkv, keymask,
+                         (unsigned short*)out, lse, L, H, scale);
+      break;
+    case 64:
+      hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, 0, s, (const unsigned short*)qkv, keymask,
+                         (unsigned short*)out, lse, L, H, scale);
+      break;
+    case 128:
+      hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, block, 0, s, (const unsigned short*)qkv, keymask,
+                         (unsigned short*)out, lse, L, H, scale);
+      break;
+    default:
+      return bd_fail(BD_ERR_UNSUPPORTED, "bd_attention_fwd: head_dim %d not in {32, 64, 128}", head_dim);
+  }
+  return bd_check_launch("bd_attention_fwd");
+}

@@ -1,0 +1,87 @@
+// Host-side driver of the denoiser forward: carves the caller's workspace and enqueues the
+// kernel chain of one forward pass on the given stream.
+#include "bd_common.h"
+#include "bidiff.h"
+
+namespace {
+inline long long align256(long long x) { return (x + 255) & ~255ll; }
+
+struct Carve {
+  long long x, h, qkv, att, ff, total;
+};
+
+Carve carve(const bd_backbone_desc& c, long long M) {
+  Carve w;
+  long long off = 0;
+  w.x = off;   off += align256(M * c.d * 4);        // residual stream fp32
+  w.h = off;   off += align256(M * c.d * 2);        // LayerNorm output bf16
+  w.qkv = off; off += align256(M * 3 * c.d * 2);    // fused q|k|v bf16
+  w.att = off; off += align256(M * c.d * 2);        // attention output bf16
+  w.ff = off;  off += align256(M * c.ffn * 2);      // GELU(fc1) bf16
+  w.total = off;
+  return w;
+}
+
+int check_desc(const bd_backbone_desc* d) {
+  BD_REQUIRE(d != nullptr, "backbone: null descriptor");
+  BD_REQUIRE(d->d > 0 && d->n_layers >= 0 && d->n_heads > 0 && d->ffn > 0 && d->vocab > 0,
+             "backbone: bad dimensions");
+  BD_REQUIRE(d->d % d->n_heads == 0, "backbone: hidden %d not divisible by heads %d", d->d, d->n_heads);
+  BD_REQUIRE(d->d % 128 == 0 && d->ffn % 128 == 0,
+             "backbone: hidden (%d) and ffn (%d) sizes must be multiples of 128", d->d, d->ffn);
+  BD_REQUIRE(d->vocab_pad % 128 == 0 && d->vocab_pad >= d->vocab, "backbone: vocab_pad must be a multiple of 128");
+  BD_REQUIRE(d->tok_emb && d->pos_emb && d->time_emb && d->lnf_g && d->lnf_b, "backbone: null table");
+  BD_REQUIRE(d->n_layers == 0 || d->layers != nullptr, "backbone: null layer array");
+  return BD_OK;
+}
+}  // namespace
+
+extern "C" long long bd_backbone_workspace_bytes(const bd_backbone_desc* desc, int B, int L) {
+  if (check_desc(desc) != BD_OK || B <= 0 || L <= 0) return -1;
+  return carve(*desc, (long long)B * L).total;
+}
+
+extern "C" int bd_backbone_forward(const bd_backbone_desc* desc, const long long* ids,
+                                   const long long* timesteps, const unsigned char* keymask, int B,
+                                   int L, void* workspace, long long workspace_bytes, void* hidden_out,
+                                   float* logits_out, void* stream) {
+  int rc = check_desc(desc);
+  if (rc != BD_OK) return rc;
+  const bd_backbone_desc& c = *desc;
+  BD_REQUIRE(ids && timesteps && workspace, "bd_backbone_forward: null operand");
+  BD_REQUIRE(B > 0 && L > 0, "bd_backbone_forward: empty batch");
+  BD_REQUIRE(L <= c.max_pos, "bd_backbone_forward: sequence length %d exceeds max_position_embeddings %d", L,
+             c.max_pos);
+  const long long M = (long long)B * L;
+  BD_REQUIRE(M < (1ll << 31), "bd_backbone_forward: too many tokens");
+  const Carve w = carve(c, M);
+  BD_REQUIRE(workspace_bytes >= w.total, "bd_backbone_forward: workspace %lld < %lld bytes", workspace_bytes,
+             w.total);
+  BD_REQUIRE(logits_out == nullptr || c.w_out != nullptr, "bd_backbone_forward: logits need w_out");
+  char* ws = (char*)workspace;
+  float* x = (float*)(ws + w.x);
+  void* h = ws + w.h;
+  void* qkv = ws + w.qkv;
+  void* att = ws + w.att;
+  void* ff = ws + w.ff;
+  const int d = c.d, F = c.ffn, Mi = (int)M;
+
+  if ((rc = bd_embed(ids, timesteps, c.tok_emb, c.pos_emb, c.time_emb, x, B, L, d, stream))) return rc;
+  for (int i = 0; i < c.n_layers; ++i) {
+    const bd_layer_weights& lw = c.layers[i];
+    if ((rc = bd_layernorm(x, lw.ln1_g, lw.ln1_b, h, nullptr, nullptr, Mi, d, c.ln_eps, stream))) return rc;
+    if ((rc = bd_gemm_bf16(h, lw.w_qkv, lw.b_qkv, qkv, Mi, 3 * d, 3 * d, d, 3 * d, 0, stream))) return rc;
+    if ((rc = bd_attention_fwd(qkv, keymask, att, nullptr, B, L, c.n_heads, d / c.n_heads, stream))) return rc;
+    if ((rc = bd_gemm_bf16(att, lw.w_o, lw.b_o, x, Mi, d, d, d, d, 2, stream))) return rc;
+    if ((rc = bd_layernorm(x, lw.ln2_g, lw.ln2_b, h, nullptr, nullptr, Mi, d, c.ln_eps, stream))) return rc;
+    if ((rc = bd_gemm_bf16(h, lw.w_fc1, lw.b_fc1, ff, Mi, F, F, d, F, 1, stream))) return rc;
+    if ((rc = bd_gemm_bf16(ff, lw.w_fc2, lw.b_fc2, x, Mi, d, d, F, d, 2, stream))) return rc;
+  }
+  void* hf = hidden_out ? hidden_out : h;
+  if ((rc = bd_layernorm(x, c.lnf_g, c.lnf_b, hf, nullptr, nullptr, Mi, d, c.ln_eps, stream))) return rc;
+  if (logits_out != nullptr) {
+    if ((rc = bd_gemm_bf16(hf, c.w_out, nullptr, logits_out, Mi, c.vocab_pad, c.vocab, d, c.vocab, 3, stream)))
+      return rc;
+  }
+  return BD_OK;
+}

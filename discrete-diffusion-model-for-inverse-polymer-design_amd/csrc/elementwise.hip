@@ -1,0 +1,188 @@
+// Bandwidth-bound kernels of the denoiser forward and the q(x_t|x_0) corruption step.
+#include "bd_common.h"
+#include "bd_rng.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------
+// Embedding sum: x[m, :] = tok[ids[m]] + pos[m % L] + time[t[m / L]]   (fp32)
+// One wave per token row, float4 per lane.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_kernel(const long long* __restrict__ ids,
+                                                    const long long* __restrict__ tsteps,
+                                                    const float* __restrict__ tok,
+                                                    const float* __restrict__ pos,
+                                                    const float* __restrict__ tim,
+                                                    float* __restrict__ x, int M, int L, int d) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const long long id = ids[row];
+  const long long t = tsteps[row / L];
+  const f32x4* a = (const f32x4*)(tok + (size_t)id * d);
+  const f32x4* b = (const f32x4*)(pos + (size_t)(row % L) * d);
+  const f32x4* c = (const f32x4*)(tim + (size_t)t * d);
+  f32x4* o = (f32x4*)(x + (size_t)row * d);
+  for (int i = lane; i < d / 4; i += 64) {
+    const f32x4 va = a[i], vb = b[i], vc = c[i];
+    f32x4 r;
+    r[0] = (va[0] + vb[0]) + vc[0]; r[1] = (va[1] + vb[1]) + vc[1];
+    r[2] = (va[2] + vb[2]) + vc[2]; r[3] = (va[3] + vb[3]) + vc[3];
+    o[i] = r;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// LayerNorm (eps inside the sqrt, affine): fp32 in, bf16 and/or fp32 out.
+// One wave per row; the row lives in registers (d <= 64*4*NV).
+// ---------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        unsigned short* __restrict__ out_bf16,
+                                                        float* __restrict__ out_f32,
+                                                        float* __restrict__ stats, int M, int d,
+                                                        float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nv = d / 4;
+  const f32x4* xr = (const f32x4*)(x + (size_t)row * d);
+  f32x4 v[NV];
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int i = lane + 64 * j;
+    v[j] = i < nv ? xr[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+  }
+  const float mean = bd_wave_sum(sum) / (float)d;
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int i = lane + 64 * j;
+    if (i < nv) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float dlt = v[j][e] - mean; sq += dlt * dlt; }
+    }
+  }
+  const float var = bd_wave_sum(sq) / (float)d;
+  const float rstd = rsqrtf(var + eps);
+  if (stats != nullptr && lane == 0) { stats[2 * (size_t)row] = mean; stats[2 * (size_t)row + 1] = rstd; }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int i = lane + 64 * j;
+    if (i < nv) {
+      const f32x4 gm = ((const f32x4*)gamma)[i], bt = ((const f32x4*)beta)[i];
+      f32x4 y;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = (v[j][e] - mean) * rstd * gm[e] + bt[e];
+      if (out_bf16 != nullptr) {
+        u32x2 w;
+        w[0] = bd_pack_bf16x2(y[0], y[1]);
+        w[1] = bd_pack_bf16x2(y[2], y[3]);
+        *(u32x2*)(out_bf16 + (size_t)row * d + 4 * i) = w;
+      }
+      if (out_f32 != nullptr) ((f32x4*)(out_f32 + (size_t)row * d))[i] = y;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// q(x_t | x_0): per-token Bernoulli masking. One thread per token, coalesced.
+// uniforms == null -> Philox stream keyed by (seed, global sequence index, t, position).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void corrupt_kernel(const long long* __restrict__ ids,
+                                                      const long long* __restrict__ attn,
+                                                      const long long* __restrict__ tsteps,
+                                                      const float* __restrict__ schedule,
+                                                      const float* __restrict__ uniforms,
+                                                      long long* __restrict__ noisy,
+                                                      unsigned char* __restrict__ indicator,
+                                                      long long n, int L, int mask_id, int pad_id,
+                                                      int bos_id, int eos_id, int has_bos, int has_eos,
+                                                      unsigned long long seed, long long seq_offset) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const long long b = i / L;
+  const int l = (int)(i - b * L);
+  const long long id = ids[i];
+  const long long t = tsteps[b];
+  const float p = schedule[t];
+  const float u = uniforms ? uniforms[i]
+                           : bd_uniform_select(seed, (uint32_t)(b + seq_offset), (uint32_t)t, (uint32_t)l);
+  bool m = u < p;
+  m = m && (attn ? (attn[i] == 1) : (id != pad_id));
+  if (has_bos) m = m && (id != bos_id);
+  if (has_eos) m = m && (id != eos_id);
+  noisy[i] = m ? (long long)mask_id : id;
+  indicator[i] = m ? 1 : 0;
+}
+
+// byte mask from an int64 attention mask (non-zero -> 1)
+__global__ __launch_bounds__(256) void mask_to_bytes_kernel(const long long* __restrict__ attn,
+                                                            unsigned char* __restrict__ out, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = attn[i] != 0 ? 1 : 0;
+}
+
+}  // namespace
+
+extern "C" int bd_embed(const long long* ids, const long long* timesteps, const float* tok_emb,
+                        const float* pos_emb, const float* time_emb, float* x, int B, int L, int d,
+                        void* stream) {
+  BD_REQUIRE(ids && timesteps && tok_emb && pos_emb && time_emb && x, "bd_embed: null operand");
+  BD_REQUIRE(B > 0 && L > 0 && d > 0 && d % 4 == 0, "bd_embed: bad shape B=%d L=%d d=%d", B, L, d);
+  const long long M = (long long)B * L;
+  BD_REQUIRE(M < (1ll << 31), "bd_embed: too many tokens");
+  hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ids,
+                     timesteps, tok_emb, pos_emb, time_emb, x, (int)M, L, d);
+  return bd_check_launch("bd_embed");
+}
+
+extern "C" int bd_layernorm(const float* x, const float* gamma, const float* beta, void* out_bf16,
+                            float* out_f32, float* stats, int M, int d, float eps, void* stream) {
+  BD_REQUIRE(x && gamma && beta && (out_bf16 || out_f32), "bd_layernorm: null operand");
+  BD_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 4096, "bd_layernorm: bad shape M=%d d=%d", M, d);
+  dim3 grid((M + 3) / 4), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  unsigned short* ob = (unsigned short*)out_bf16;
+  const int nv = (d / 4 + 63) / 64;
+  if (nv <= 1)
+    hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, gamma, beta, ob, out_f32, stats, M, d, eps);
+  else if (nv <= 2)
+    hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, gamma, beta, ob, out_f32, stats, M, d, eps);
+  else if (nv <= 4)
+    hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, gamma, beta, ob, out_f32, stats, M, d, eps);
+  else if (nv <= 8)
+    hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, x, gamma, beta, ob, out_f32, stats, M, d, eps);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<16>, grid, block, 0, s, x, gamma, beta, ob, out_f32, stats, M, d, eps);
+  return bd_check_launch("bd_layernorm");
+}
+
+extern "C" int bd_corrupt(const long long* ids, const long long* attention_mask,
+                          const long long* timesteps, const float* schedule, int schedule_len,
+                          const float* uniforms, long long* noisy_ids, unsigned char* mask_indicator,
+                          int B, int L, int mask_id, int pad_id, int bos_id, int eos_id,
+                          unsigned long long seed, long long seq_offset, void* stream) {
+  BD_REQUIRE(ids && timesteps && schedule && noisy_ids && mask_indicator, "bd_corrupt: null operand");
+  BD_REQUIRE(B >= 0 && L >= 0 && schedule_len > 0, "bd_corrupt: bad shape");
+  const long long n = (long long)B * L;
+  if (n == 0) return BD_OK;
+  hipLaunchKernelGGL(corrupt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     ids, attention_mask, timesteps, schedule, uniforms, noisy_ids, mask_indicator, n, L,
+                     mask_id, pad_id, bos_id, eos_id, bos_id >= 0 ? 1 : 0, eos_id >= 0 ? 1 : 0, seed,
+                     seq_offset);
+  return bd_check_launch("bd_corrupt");
+}
+
+extern "C" int bd_mask_to_bytes(const long long* attention_mask, unsigned char* out, long long n,
+                                void* stream) {
+  BD_REQUIRE(attention_mask && out && n >= 0, "bd_mask_to_bytes: bad argument");
+  if (n == 0) return BD_OK;
+  hipLaunchKernelGGL(mask_to_bytes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, attention_mask, out, n);
+  return bd_check_launch("bd_mask_to_bytes");
+}

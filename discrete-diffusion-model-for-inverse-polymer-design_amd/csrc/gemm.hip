@@ -1,0 +1,243 @@
+// bf16 MFMA GEMM for the denoiser's Linear layers on gfx950:
+//     C[M,N] = A[M,K] * W[N,K]^T (+ bias) with a fused epilogue.
+// Both operands are K-contiguous (torch.nn.Linear keeps W as [out,in]), which is the
+// natural MFMA operand order: every fragment is one 16-byte LDS read.
+//
+// Tiling: 128x128 output tile per 256-thread workgroup (4 waves, 2x2, 64x64 each),
+// BK = 64, 16x16x32 bf16 MFMA, fp32 accumulate. The weight rows are the MFMA "A"
+// operand and the activation rows the "B" operand, so a lane ends up holding
+// consecutive output columns of ONE activation row; the weight rows are additionally
+// permuted inside each wave so that a lane's 16 accumulators of one m-tile are 16
+// consecutive n: the epilogue stores 16-byte vectors straight from registers.
+#include "bd_common.h"
+#include "bd_prof.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * BK * 2;  // one operand tile: 128 rows x 128 B
+
+enum Epi : int {
+  EPI_BIAS_BF16 = 0,       // out bf16 = acc + bias
+  EPI_BIAS_GELU_BF16 = 1,  // out bf16 = gelu(acc + bias)   (erf form, F.gelu default)
+  EPI_BIAS_RESID_F32 = 2,  // out fp32 += acc + bias        (residual stream, in place)
+  EPI_F32 = 3,             // out fp32 = acc (+ bias if given), columns >= n_real dropped
+  EPI_BF16_NOBIAS_T = 4    // reserved
+};
+
+struct GemmArgs {
+  const unsigned short* A;   // [M, K] bf16
+  const unsigned short* W;   // [Npad, K] bf16, Npad % 128 == 0 (zero rows past n_real)
+  const float* bias;         // [n_real] or null
+  void* out;                 // bf16 or fp32, row stride ldc elements
+  int M, Npad, K, n_real, ldc;
+  int tiles_n, n_tiles;
+};
+
+__device__ __forceinline__ int swz_a(int row) { return row & 7; }
+__device__ __forceinline__ int swz_w(int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); }
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];
+  unsigned char* const As = smem;                   // 2 buffers
+  unsigned char* const Ws = smem + 2 * TILE_BYTES;  // 2 buffers
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int g = lane >> 4, c = lane & 15;
+
+  // XCD-aware, bijective remap: blocks that share an XCD (id % 8) walk a contiguous
+  // run of tiles (n fastest), so the A row-panel is re-read from that XCD's L2.
+  int tile;
+  {
+    const int nwg = p.n_tiles, orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int m0 = (tile / p.tiles_n) * BM;
+  const int n0 = (tile % p.tiles_n) * BN;
+  const int K = p.K;
+
+  // ---- staging addresses: thread -> (row = tid/8 + 32 i, 16-byte chunk = tid%8)
+  const int srow = tid >> 3, sch = tid & 7;
+  const unsigned short* ga[4];
+  const unsigned short* gw[4];
+  int offa[4], offw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = srow + 32 * i;
+    int am = m0 + r; am = am < p.M ? am : p.M - 1;
+    ga[i] = p.A + (size_t)am * K + sch * 8;
+    gw[i] = p.W + (size_t)(n0 + r) * K + sch * 8;
+    offa[i] = r * 128 + ((sch ^ swz_a(r)) << 4);
+    offw[i] = r * 128 + ((sch ^ swz_w(r)) << 4);
+  }
+
+  // ---- fragment read offsets (per kk add 64 B chunk pairs through the XOR)
+  int fa_row[4], fw_row[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    fa_row[t] = wm * 64 + 16 * t + c;                          // activation row (MFMA col)
+    fw_row[t] = wn * 64 + 16 * (c >> 2) + 4 * t + (c & 3);     // permuted weight row
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ra[4], rw[4];
+  const int nk = K / BK;
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ra[i] = *(const u32x4*)(ga[i]);
+    rw[i] = *(const u32x4*)(gw[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    *(u32x4*)(As + offa[i]) = ra[i];
+    *(u32x4*)(Ws + offw[i]) = rw[i];
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const bool more = (kt + 1) < nk;
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ra[i] = *(const u32x4*)(ga[i] + (kt + 1) * BK);
+        rw[i] = *(const u32x4*)(gw[i] + (kt + 1) * BK);
+      }
+    }
+    const unsigned char* Ab = As + buf * TILE_BYTES;
+    const unsigned char* Wb = Ws + buf * TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ch = 4 * kk + g;
+      bf16x8 fa[4], fw[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fa[t] = *(const bf16x8*)(Ab + fa_row[t] * 128 + ((ch ^ swz_a(fa_row[t])) << 4));
+        fw[t] = *(const bf16x8*)(Wb + fw_row[t] * 128 + ((ch ^ swz_w(fw_row[t])) << 4));
+      }
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+          acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[tn], fa[tm], acc[tn][tm], 0, 0, 0);
+    }
+    if (more) {
+      unsigned char* An = As + (buf ^ 1) * TILE_BYTES;
+      unsigned char* Wn = Ws + (buf ^ 1) * TILE_BYTES;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        *(u32x4*)(An + offa[i]) = ra[i];
+        *(u32x4*)(Wn + offw[i]) = rw[i];
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane (g, c) holds, for m-tile tm, n = nb + 4 tn + r (16 consecutive)
+  const int nb = n0 + wn * 64 + 16 * g;
+  float bv[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) bv[j] = 0.f;
+  if (p.bias != nullptr) {
+    if (EPI == EPI_F32) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) bv[j] = (nb + j) < p.n_real ? p.bias[nb + j] : 0.f;
+    } else {
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) {
+        const f32x4 t = *(const f32x4*)(p.bias + nb + 4 * j4);
+        bv[4 * j4 + 0] = t[0]; bv[4 * j4 + 1] = t[1]; bv[4 * j4 + 2] = t[2]; bv[4 * j4 + 3] = t[3];
+      }
+    }
+  }
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+    const int m = m0 + wm * 64 + 16 * tm + c;
+    if (m >= p.M) continue;
+    float v[16];
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[4 * tn + r] = acc[tn][tm][r] + bv[4 * tn + r];
+    if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16) {
+      if (EPI == EPI_BIAS_GELU_BF16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = gelu_erf(v[j]);
+      }
+      unsigned short* o = (unsigned short*)p.out + (size_t)m * p.ldc + nb;
+      u32x4 lo, hi;
+      lo[0] = bd_pack_bf16x2(v[0], v[1]);   lo[1] = bd_pack_bf16x2(v[2], v[3]);
+      lo[2] = bd_pack_bf16x2(v[4], v[5]);   lo[3] = bd_pack_bf16x2(v[6], v[7]);
+      hi[0] = bd_pack_bf16x2(v[8], v[9]);   hi[1] = bd_pack_bf16x2(v[10], v[11]);
+      hi[2] = bd_pack_bf16x2(v[12], v[13]); hi[3] = bd_pack_bf16x2(v[14], v[15]);
+      *(u32x4*)(o) = lo;
+      *(u32x4*)(o + 8) = hi;
+    } else if (EPI == EPI_BIAS_RESID_F32) {
+      float* o = (float*)p.out + (size_t)m * p.ldc + nb;
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) {
+        f32x4 x = *(const f32x4*)(o + 4 * j4);
+        x[0] += v[4 * j4 + 0]; x[1] += v[4 * j4 + 1]; x[2] += v[4 * j4 + 2]; x[3] += v[4 * j4 + 3];
+        *(f32x4*)(o + 4 * j4) = x;
+      }
+    } else {  // EPI_F32, ragged N
+      float* o = (float*)p.out + (size_t)m * p.ldc;
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (nb + j < p.n_real) o[nb + j] = v[j];
+    }
+  }
+}
+
+template <int EPI>
+int launch(const GemmArgs& a, hipStream_t s) {
+  void* tok = bd_prof_on() ? bd_prof_begin(s) : nullptr;
+  hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(a.n_tiles), dim3(256), 0, s, a);
+  if (tok) bd_prof_end(tok, s, 2.0 * (double)a.M * (double)a.n_real * (double)a.K);
+  return bd_check_launch("bd_gemm_bf16");
+}
+
+}  // namespace
+
+// epilogue: 0 bias->bf16, 1 bias+gelu->bf16, 2 fp32 out += acc+bias, 3 fp32 out (ragged n)
+extern "C" int bd_gemm_bf16(const void* A, const void* W, const float* bias, void* out,
+                            int M, int n_pad, int n_real, int K, int ldc, int epilogue,
+                            void* stream) {
+  BD_REQUIRE(A && W && out, "bd_gemm_bf16: null operand");
+  BD_REQUIRE(M > 0 && K > 0 && n_pad > 0, "bd_gemm_bf16: empty shape M=%d N=%d K=%d", M, n_pad, K);
+  BD_REQUIRE(n_pad % BN == 0, "bd_gemm_bf16: weight rows %d must be padded to a multiple of %d", n_pad, BN);
+  BD_REQUIRE(K % BK == 0, "bd_gemm_bf16: K=%d must be a multiple of %d", K, BK);
+  BD_REQUIRE(n_real > 0 && n_real <= n_pad, "bd_gemm_bf16: n_real=%d out of range", n_real);
+  BD_REQUIRE(epilogue == EPI_F32 || (n_real == n_pad && (ldc % 8) == 0),
+             "bd_gemm_bf16: vector epilogues need n_real == n_pad and ldc %% 8 == 0");
+  BD_REQUIRE(ldc >= n_real, "bd_gemm_bf16: ldc=%d < n=%d", ldc, n_real);
+  GemmArgs a;
+  a.A = (const unsigned short*)A; a.W = (const unsigned short*)W; a.bias = bias; a.out = out;
+  a.M = M; a.Npad = n_pad; a.K = K; a.n_real = n_real; a.ldc = ldc;
+  a.tiles_n = n_pad / BN;
+  const long long tiles_m = ((long long)M + BM - 1) / BM;
+  const long long nt = tiles_m * a.tiles_n;
+  BD_REQUIRE(nt < (1ll << 31), "bd_gemm_bf16: too many tiles");
+  a.n_tiles = (int)nt;
+  hipStream_t s = (hipStream_t)stream;
+  switch (epilogue) {
+    case EPI_BIAS_BF16: return launch<EPI_BIAS_BF16>(a, s);
+    case EPI_BIAS_GELU_BF16: return launch<EPI_BIAS_GELU_BF16>(a, s);
+    case EPI_BIAS_RESID_F32: return launch<EPI_BIAS_RESID_F32>(a, s);
+    case EPI_F32: return launch<EPI_F32>(a, s);
+    default: return bd_fail(BD_ERR_ARG, "bd_gemm_bf16: unknown epilogue %d", epilogue);
+  }
+}

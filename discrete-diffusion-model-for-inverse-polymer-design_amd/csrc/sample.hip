@@ -1,0 +1,654 @@
+// One reverse-diffusion unmasking step and the post-loop repairs, one wavefront per
+// sequence (gfx950, wave64). The step is the explicit-uniform restatement of the
+// reference samplers' inner loop:
+//   * k = ktable[n_masked] positions are chosen as the k smallest per-position keys
+//     (distribution-identical to randperm(n)[:k]); ties go to the lower position;
+//   * each chosen position draws argmax_v(logit[v] + gumbel(u[v])) (distribution-
+//     identical to multinomial(softmax(logit))), ties to the lower v; a row with no
+//     allowed entry falls back to a uniform pick among the non-special ids;
+//   * draws are sequential inside a sequence and apply the same in-step constraint
+//     updates as the reference.
+// Two logits sources: LOGITS mode edits a full [B,L,V] fp32 tensor in place exactly as
+// the reference mutates its `logits` (divide by temperature, -inf edits, boosts), which
+// is what the post-loop repairs consume at t = 1; HIDDEN mode computes vocabulary
+// logits only for the chosen rows from the final hidden states and the output
+// projection, never materialising [B,L,V].
+#include "bd_common.h"
+#include "bd_rng.h"
+#include "bidiff.h"
+
+namespace {
+
+constexpr int MAXL = BD_SAMPLE_MAX_L;
+constexpr int MAXV = BD_SAMPLE_MAX_V;
+constexpr int MAXD = BD_SAMPLE_MAX_D;
+constexpr int MAXR = BD_SAMPLE_MAX_RING;
+
+// per-position flags in LDS
+constexpr int PF_MASK0 = 1, PF_FIXED = 2, PF_DYN_BOND = 4, PF_DYN_CLOSE = 8, PF_CLOSE = 16, PF_OPEN = 32,
+              PF_BOND = 64, PF_BOOST = 128;
+
+struct Smem {
+  int ids[MAXL];
+  unsigned int key[MAXL];
+  float col[MAXL];
+  short sel[MAXL];
+  unsigned char pf[MAXL];
+  float row[MAXV];
+  float h[MAXD];
+  int ringcnt[MAXR];
+  unsigned char ringforbid[MAXR];
+};
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned int lo = __shfl_xor((unsigned int)v, o, 64);
+    const unsigned int hi = __shfl_xor((unsigned int)(v >> 32), o, 64);
+    const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+    v = w < v ? w : v;
+  }
+  return v;
+}
+
+// (score, index) argmax over the wave, ties to the lower index; idx < 0 = no candidate.
+__device__ __forceinline__ void wave_argmax(float& best, int& idx) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    const bool take = (oi >= 0) && (idx < 0 || ob > best || (ob == best && oi < idx));
+    if (take) { best = ob; idx = oi; }
+  }
+}
+
+// Is token v (class bits tf) forbidden at masked position l?
+__device__ __forceinline__ bool forbidden_at(const bd_step_args& p, const Smem& s, int l, int v, int tf,
+                                             bool cnt_forbid, bool eos_forbid) {
+  if (tf & BD_TF_SPECIAL) return true;
+  if ((tf & BD_TF_EOS) && eos_forbid) return true;
+  if (!p.use_constraints) return false;
+  if (cnt_forbid && (tf & BD_TF_COUNTED)) return true;
+  if (p.variant & BD_VB_SYNTAX) {
+    const int f = s.pf[l];
+    if ((tf & BD_TF_CLOSE) && (f & (PF_CLOSE | PF_DYN_CLOSE))) return true;
+    if ((tf & BD_TF_OPEN) && (f & PF_OPEN)) return true;
+    if ((tf & BD_TF_BOND) && (f & (PF_BOND | PF_DYN_BOND))) return true;
+    if ((tf & BD_TF_RING) && s.ringforbid[p.ring_slot[v]]) return true;
+  }
+  return false;
+}
+
+__global__ __launch_bounds__(64) void sample_step_kernel(bd_step_args p) {
+  __shared__ Smem s;
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x;
+  const int L = p.L, V = p.V, d = p.d;
+  const int CH = (L + 63) / 64;  // contiguous positions per lane
+  const int l0 = lane * CH;
+  long long* ids_g = p.ids + (size_t)b * L;
+  const bool cons = p.use_constraints != 0;
+  const bool syntax = cons && (p.variant & BD_VB_SYNTAX);
+  const bool logits_mode = p.hidden == nullptr;
+  float* lg = p.logits ? p.logits + (size_t)b * L * V : nullptr;
+  const uint32_t seq = (uint32_t)(p.seq_offset + b);
+  const unsigned short* hidden = (const unsigned short*)p.hidden;
+  const unsigned short* wout = (const unsigned short*)p.wout;
+
+  // ---- load ids, start-of-step flags
+  for (int l = lane; l < L; l += 64) {
+    const int id = (int)ids_g[l];
+    s.ids[l] = id;
+    int f = (id == p.mask_id) ? PF_MASK0 : 0;
+    if ((p.variant & BD_VB_FIXED) && p.fixed && p.fixed[(size_t)b * L + l]) f |= PF_FIXED;
+    s.pf[l] = (unsigned char)f;
+  }
+  for (int r = lane; r < p.R; r += 64) { s.ringcnt[r] = 0; s.ringforbid[r] = 0; }
+  __syncthreads();
+
+  // ---- per-sequence counts: masked, selectable, counted-token total
+  int n_mask = 0, n_sel = 0, total = 0;
+  for (int j = 0; j < CH; ++j) {
+    const int l = l0 + j;
+    if (l < L) {
+      const int f = s.pf[l];
+      if (f & PF_MASK0) { n_mask++; if (!(f & PF_FIXED)) n_sel++; }
+      else total += p.contrib[s.ids[l]];
+    }
+  }
+  n_mask = bd_wave_sum_i(n_mask);
+  n_sel = bd_wave_sum_i(n_sel);
+  total = bd_wave_sum_i(total);
+  bool cnt_forbid = cons && total >= 2;
+  const bool natural = (p.variant & BD_VB_NATURAL_EOS) != 0;
+  bool eos_forbid = true;  // EOS is an ordinary forbidden special unless natural-EOS mode
+  if (natural) eos_forbid = p.has_eos[b] != 0;
+
+  // ---- SMILES syntax state from the start-of-step ids
+  if (syntax) {
+    int dloc = 0, mloc = 0, lastnm = -1;
+    for (int j = 0; j < CH; ++j) {
+      const int l = l0 + j;
+      if (l < L) {
+        const int id = s.ids[l];
+        dloc += (int)(p.open_id >= 0 && id == p.open_id) - (int)(p.close_id >= 0 && id == p.close_id);
+        if (s.pf[l] & PF_MASK0) mloc++; else lastnm = l;
+        const int slot = p.ring_slot[id];
+        if (slot >= 0) atomicAdd(&s.ringcnt[slot], 1);
+      }
+    }
+    int dinc = dloc, minc = mloc, pmax = lastnm;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int dv = __shfl_up(dinc, o, 64);
+      const int pv = __shfl_up(pmax, o, 64);
+      const int mv = __shfl_down(minc, o, 64);
+      if (lane >= o) { dinc += dv; pmax = pv > pmax ? pv : pmax; }
+      if (lane + o < 64) minc += mv;
+    }
+    int depth = dinc - dloc;             // open - close over positions before this chunk
+    int msuf = minc;                     // masks at positions >= l0
+    int prev = __shfl_up(pmax, 1, 64);   // last non-mask index before this chunk
+    if (lane == 0) prev = -1;
+    const bool have_paren = (p.open_id >= 0) || (p.close_id >= 0);
+    const bool have_bond = p.n_bond > 0;
+    for (int j = 0; j < CH; ++j) {
+      const int l = l0 + j;
+      if (l < L) {
+        const int id = s.ids[l];
+        int f = s.pf[l];
+        const bool is_m = (f & PF_MASK0) != 0;
+        if (!is_m) prev = l;
+        if (is_m) {
+          if (have_paren) {
+            if (p.close_id >= 0 && depth <= 0) f |= PF_CLOSE;
+            if (p.open_id >= 0 && depth + 2 > msuf) f |= PF_OPEN;
+          }
+          if (have_bond) {
+            const int pid = prev >= 0 ? s.ids[prev] : -1;
+            bool inv = prev < 0;
+            if (!inv) {
+              inv = (p.bos_id >= 0 && pid == p.bos_id) || (p.eos_id >= 0 && pid == p.eos_id) ||
+                    (p.pad_id >= 0 && pid == p.pad_id) || (p.open_id >= 0 && pid == p.open_id) ||
+                    (p.close_id >= 0 && pid == p.close_id) || (p.tok_flags[pid] & BD_TF_BOND);
+            }
+            if (inv) f |= PF_BOND;
+            if (p.open_id >= 0 && p.close_id >= 0 && pid == p.open_id) f |= PF_CLOSE;
+          }
+          s.pf[l] = (unsigned char)f;
+          msuf--;
+        }
+        depth += (int)(p.open_id >= 0 && id == p.open_id) - (int)(p.close_id >= 0 && id == p.close_id);
+      }
+    }
+    __syncthreads();
+    int open_cnt = 0;
+    for (int r = lane; r < p.R; r += 64) open_cnt += (s.ringcnt[r] == 1);
+    open_cnt = bd_wave_sum_i(open_cnt);
+    const bool forbid_new = n_mask <= open_cnt;
+    for (int r = lane; r < p.R; r += 64) {
+      const int cnt = s.ringcnt[r];
+      s.ringforbid[r] = (cnt >= 2) || (forbid_new && cnt != 1);
+    }
+  }
+  __syncthreads();
+
+  // ---- LOGITS mode: the whole tensor becomes logits / temperature with the static edits
+  if (logits_mode) {
+    const int tot = L * V;
+    for (int i = lane; i < tot; i += 64) {
+      const int l = i / V, v = i - l * V;
+      float x = lg[i] / p.temperature;
+      if ((s.pf[l] & PF_MASK0) && forbidden_at(p, s, l, v, p.tok_flags[v], cnt_forbid, eos_forbid))
+        x = -INFINITY;
+      lg[i] = x;
+    }
+    __syncthreads();
+  }
+
+  // ---- SELFIES urgency boost of the placeholder when few masked slots remain
+  if (cons && (p.variant & BD_VB_URGENCY)) {
+    const int needed = 2 - total;
+    if (needed > 0 && n_mask > 0 && n_mask <= 5 * needed) {
+      const int bid = p.boost_id;
+      if (!logits_mode) {
+        for (int k = lane; k < d; k += 64) s.h[k] = bd_bf16_to_f32(wout[(size_t)bid * d + k]);
+        __syncthreads();
+      }
+      float cmax = -INFINITY;
+      for (int j = 0; j < CH; ++j) {
+        const int l = l0 + j;
+        if (l < L) {
+          float x;
+          if (logits_mode) {
+            x = lg[(size_t)l * V + bid];
+          } else {
+            const unsigned short* hr = hidden + ((size_t)b * L + l) * d;
+            float acc = 0.f;
+            for (int k = 0; k < d; k += 8) {
+              const u32x4 w = *(const u32x4*)(hr + k);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                acc += __uint_as_float(w[e] << 16) * s.h[k + 2 * e];
+                acc += __uint_as_float(w[e] & 0xffff0000u) * s.h[k + 2 * e + 1];
+              }
+            }
+            if (lg) lg[(size_t)l * V + bid] = acc;  // raw dump for replay
+            x = acc / p.temperature;
+          }
+          s.col[l] = x;
+          cmax = fmaxf(cmax, x);
+        }
+      }
+      cmax = bd_wave_max(cmax);
+      __syncthreads();
+      int kk = needed < n_mask ? needed : n_mask;
+      // any masked slot whose softmax-over-positions weight is certainly non-zero?
+      int anyv = 0;
+      for (int j = 0; j < CH; ++j) {
+        const int l = l0 + j;
+        if (l < L && (s.pf[l] & PF_MASK0) && s.col[l] >= cmax - 80.0f) anyv = 1;
+      }
+      anyv = bd_wave_sum_i(anyv);
+      if (anyv > 0) {
+        for (int round = 0; round < kk; ++round) {
+          float best = -INFINITY; int idx = -1;
+          for (int j = 0; j < CH; ++j) {
+            const int l = l0 + j;
+            if (l < L && (s.pf[l] & PF_MASK0) && !(s.pf[l] & PF_BOOST)) {
+              const float x = s.col[l];
+              if (idx < 0 || x > best) { best = x; idx = l; }
+            }
+          }
+          wave_argmax(best, idx);
+          if (idx >= 0 && lane == 0) {
+            s.pf[idx] |= PF_BOOST;
+            if (logits_mode) lg[(size_t)idx * V + bid] = 100.0f;
+          }
+          __syncthreads();
+        }
+      }
+    }
+  }
+
+  // ---- choose the k smallest keys among the selectable masked positions
+  int k_sel = 0;
+  if (n_sel > 0) {
+    k_sel = p.ktable[n_sel];
+    k_sel = k_sel < 1 ? 1 : (k_sel > n_sel ? n_sel : k_sel);
+    for (int l = lane; l < L; l += 64) {
+      const int f = s.pf[l];
+      unsigned int kb = 0xffffffffu;
+      if ((f & PF_MASK0) && !(f & PF_FIXED)) {
+        const float u = p.u_sel ? p.u_sel[(size_t)b * L + l]
+                                : bd_uniform_select(p.seed, seq, (uint32_t)p.t, (uint32_t)l);
+        kb = __float_as_uint(u) & 0x7fffffffu;
+      }
+      s.key[l] = kb;
+    }
+    __syncthreads();
+    for (int round = 0; round < k_sel; ++round) {
+      unsigned long long best = ~0ull;
+      for (int j = 0; j < CH; ++j) {
+        const int l = l0 + j;
+        if (l < L) {
+          const unsigned int kb = s.key[l];
+          if (kb != 0xffffffffu) {
+            const unsigned long long ck = ((unsigned long long)kb << 32) | (unsigned int)l;
+            best = ck < best ? ck : best;
+          }
+        }
+      }
+      best = wave_min_u64(best);
+      const int pos = (int)(best & 0xffffffffu);
+      if (lane == 0) { s.sel[round] = (short)pos; s.key[pos] = 0xffffffffu; }
+      __syncthreads();
+    }
+    if (p.variant & BD_VB_SORTED) {
+      // ascending-position order: rank each chosen position among the chosen
+      for (int i = lane; i < k_sel; i += 64) s.key[i] = (unsigned int)s.sel[i];
+      __syncthreads();
+      for (int i = lane; i < k_sel; i += 64) {
+        const unsigned int mine = s.key[i];
+        int rank = 0;
+        for (int j = 0; j < k_sel; ++j) rank += (s.key[j] < mine);
+        s.sel[rank] = (short)mine;
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- sequential draws
+  for (int it = 0; it < k_sel; ++it) {
+    const int pos = s.sel[it];
+    if (s.ids[pos] != p.mask_id) continue;  // filled by an EOS termination earlier in this step
+    const int pflag = s.pf[pos];
+    if (!logits_mode) {
+      const unsigned short* hr = hidden + ((size_t)b * L + pos) * d;
+      for (int k = lane * 8; k < d; k += 512) {
+        const u32x4 w = *(const u32x4*)(hr + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s.h[k + 2 * e] = __uint_as_float(w[e] << 16);
+          s.h[k + 2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+        }
+      }
+      __syncthreads();
+    }
+    float best = -INFINITY; int idx = -1;
+    for (int v = lane; v < V; v += 64) {
+      float x;
+      if (logits_mode) {
+        x = lg[(size_t)pos * V + v];
+      } else {
+        const unsigned short* wr = wout + (size_t)v * d;
+        float acc = 0.f;
+        for (int k = 0; k < d; k += 8) {
+          const u32x4 w = *(const u32x4*)(wr + k);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc += __uint_as_float(w[e] << 16) * s.h[k + 2 * e];
+            acc += __uint_as_float(w[e] & 0xffff0000u) * s.h[k + 2 * e + 1];
+          }
+        }
+        if (lg) lg[(size_t)pos * V + v] = acc;  // raw dump for replay
+        x = acc / p.temperature;
+        if ((pflag & PF_BOOST) && v == p.boost_id) x = 100.0f;
+        if (forbidden_at(p, s, pos, v, p.tok_flags[v], cnt_forbid, eos_forbid)) x = -INFINITY;
+      }
+      if (x > -INFINITY) {
+        const float u = p.u_tok ? p.u_tok[((size_t)b * L + pos) * V + v]
+                                : bd_uniform_token(p.seed, seq, (uint32_t)p.t, (uint32_t)pos, (uint32_t)v);
+        const float sc = x + bd_gumbel(u);
+        if (idx < 0 || sc > best) { best = sc; idx = v; }
+      }
+    }
+    wave_argmax(best, idx);
+    int tok = idx;
+    if (tok < 0) {
+      const float u0 = p.u_tok ? p.u_tok[((size_t)b * L + pos) * V]
+                               : bd_uniform_token(p.seed, seq, (uint32_t)p.t, (uint32_t)pos, 0u);
+      int j = (int)(u0 * (float)p.n_ns);
+      j = j < 0 ? 0 : (j >= p.n_ns ? p.n_ns - 1 : j);
+      tok = p.non_special[j];
+    }
+    __syncthreads();
+    if (lane == 0) s.ids[pos] = tok;
+    __syncthreads();
+
+    if (natural && tok == p.eos_id) {
+      // the sequence ends here: pad the tail, hide it from attention, stop this row
+      for (int l = pos + 1 + lane; l < L; l += 64) {
+        s.ids[l] = p.pad_id;
+        if (p.attn) p.attn[(size_t)b * L + l] = 0;
+        if (p.keymask) p.keymask[(size_t)b * L + l] = 0;
+      }
+      if (lane == 0) p.has_eos[b] = 1;
+      __syncthreads();
+      break;
+    }
+
+    if (cons) {
+      const int tf = p.tok_flags[tok];
+      if (tf & BD_TF_COUNTED) {
+        int tot2 = 0;
+        for (int j = 0; j < CH; ++j) {
+          const int l = l0 + j;
+          if (l < L && s.ids[l] != p.mask_id) tot2 += p.contrib[s.ids[l]];
+        }
+        tot2 = bd_wave_sum_i(tot2);
+        if (tot2 >= 2) {
+          cnt_forbid = true;
+          if (logits_mode) {
+            for (int l = lane; l < L; l += 64) {
+              if (s.ids[l] == p.mask_id && !(s.pf[l] & PF_FIXED))
+                for (int q = 0; q < p.n_counted; ++q) lg[(size_t)l * V + p.counted_ids[q]] = -INFINITY;
+            }
+          }
+        }
+      } else if ((p.variant & BD_VB_SYNTAX) && (tf & BD_TF_BOND)) {
+        const int np = pos + 1;
+        if (np < L && s.ids[np] == p.mask_id) {
+          if (lane == 0) s.pf[np] |= PF_DYN_BOND;
+          if (logits_mode)
+            for (int q = lane; q < p.n_bond; q += 64) lg[(size_t)np * V + p.bond_ids[q]] = -INFINITY;
+        }
+      } else if ((p.variant & BD_VB_SYNTAX) && p.open_id >= 0 && tok == p.open_id) {
+        const int np = pos + 1;
+        if (np < L && s.ids[np] == p.mask_id) {
+          if (lane == 0) s.pf[np] |= PF_DYN_CLOSE;
+          // the reference indexes column close_id even when it is -1 (= last column)
+          if (logits_mode && lane == 0) lg[(size_t)np * V + (p.close_id >= 0 ? p.close_id : V - 1)] = -INFINITY;
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  __syncthreads();
+  for (int l = lane; l < L; l += 64) ids_g[l] = (long long)s.ids[l];
+}
+
+// -----------------------------------------------------------------------------------
+// Post-loop repairs on the final ids with the t = 1 logits.
+// -----------------------------------------------------------------------------------
+struct FixSmem {
+  int ids[MAXL];
+  unsigned char mark[MAXL];
+};
+
+// argmax over the vocabulary row with an exclusion predicate; first maximum wins,
+// an all -inf row gives 0 (torch.argmax convention).
+template <typename Excl>
+__device__ __forceinline__ int row_argmax(const float* row, int V, int lane, Excl excl) {
+  float best = -INFINITY; int idx = -1;
+  for (int v = lane; v < V; v += 64) {
+    float x = row[v];
+    if (excl(v)) x = -INFINITY;
+    if (idx < 0 || x > best) { best = x; idx = v; }
+  }
+  wave_argmax(best, idx);
+  return idx < 0 ? 0 : idx;
+}
+
+// Keep/choose `want` positions with the largest column value among candidates
+// (cand[l] != 0), ties to the lower position; chosen positions get mark |= 2.
+__device__ __forceinline__ void pick_top_positions(FixSmem& s, const float* lg, int L, int V, int col,
+                                                   int want, int lane) {
+  const int CH = (L + 63) / 64, l0 = lane * CH;
+  for (int round = 0; round < want; ++round) {
+    float best = -INFINITY; int idx = -1;
+    for (int j = 0; j < CH; ++j) {
+      const int l = l0 + j;
+      if (l < L && s.mark[l] == 1) {
+        const float x = lg[(size_t)l * V + col];
+        if (idx < 0 || x > best) { best = x; idx = l; }
+      }
+    }
+    wave_argmax(best, idx);
+    if (idx >= 0 && lane == 0) s.mark[idx] = 3;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(64) void fixup_kernel(bd_fix_args p) {
+  __shared__ FixSmem s;
+  const int lane = threadIdx.x, b = blockIdx.x;
+  const int L = p.L, V = p.V;
+  const int CH = (L + 63) / 64, l0 = lane * CH;
+  long long* ids_g = p.ids + (size_t)b * L;
+  const float* lg = p.logits ? p.logits + (size_t)b * L * V : nullptr;
+  for (int l = lane; l < L; l += 64) s.ids[l] = (int)ids_g[l];
+  __syncthreads();
+
+  // ---- natural-EOS rows that never drew EOS get one appended
+  if (p.natural_eos && p.has_eos && p.has_eos[b] == 0) {
+    int last = -1;
+    for (int j = 0; j < CH; ++j) {
+      const int l = l0 + j;
+      if (l < L && s.ids[l] != p.pad_id) last = l;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(last, o, 64); last = v > last ? v : last; }
+    if (last >= 0) {
+      if (s.ids[last] == p.mask_id) {
+        if (lane == 0) s.ids[last] = p.eos_id;
+      } else if (last + 1 < L) {
+        if (lane == 0) s.ids[last + 1] = p.eos_id;
+        for (int l = last + 2 + lane; l < L; l += 64) {
+          s.ids[l] = p.pad_id;
+          if (p.attn) p.attn[(size_t)b * L + l] = 0;
+          if (p.keymask) p.keymask[(size_t)b * L + l] = 0;
+        }
+      }
+    }
+    if (lane == 0) p.has_eos[b] = 1;
+    __syncthreads();
+  }
+
+  if (p.do_fix && lg != nullptr) {
+    // ---- exactly `target` star / placeholder tokens
+    const int cid = p.count_id;
+    int n_c = 0;
+    for (int j = 0; j < CH; ++j) { const int l = l0 + j; if (l < L && s.ids[l] == cid) n_c++; }
+    n_c = bd_wave_sum_i(n_c);
+    if (n_c > p.target) {
+      for (int l = lane; l < L; l += 64) s.mark[l] = (s.ids[l] == cid) ? 1 : 0;
+      __syncthreads();
+      pick_top_positions(s, lg, L, V, cid, p.target, lane);
+      for (int l = 0; l < L; ++l) {
+        if (s.mark[l] == 1) {  // an extra one: best other token
+          const int tok = row_argmax(lg + (size_t)l * V, V, lane, [&](int v) {
+            if (v == cid) return true;
+            for (int q = 0; q < p.n_excl; ++q) if (v == p.excl[q]) return true;
+            return false;
+          });
+          __syncthreads();
+          if (lane == 0) s.ids[l] = tok;
+        }
+      }
+      __syncthreads();
+    } else if (n_c < p.target) {
+      const int needed = p.target - n_c;
+      int nvalid = 0;
+      for (int l = lane; l < L; l += 64) {
+        const int id = s.ids[l];
+        const bool ok = id != p.bos_id && id != p.eos_id && id != p.pad_id && id != cid;
+        s.mark[l] = ok ? 1 : 0;
+        nvalid += ok;
+      }
+      nvalid = bd_wave_sum_i(nvalid);
+      __syncthreads();
+      if (nvalid >= needed) {
+        pick_top_positions(s, lg, L, V, cid, needed, lane);
+        for (int l = lane; l < L; l += 64) if (s.mark[l] == 3) s.ids[l] = cid;
+        __syncthreads();
+      }
+    }
+
+    if (p.smiles_syntax) {
+      auto paren_excl = [&](int v) {
+        return v == p.close_id || v == p.open_id || v == p.mask_id || v == p.pad_id || v == p.bos_id ||
+               v == p.eos_id || (p.close_id < 0 && v == V - 1) || (p.open_id < 0 && v == V - 1);
+      };
+      // ---- parentheses: left-to-right drop unmatched ')', right-to-left drop unmatched '('
+      if (p.open_id >= 0 || p.close_id >= 0) {
+        int depth = 0;
+        for (int l = 0; l < L; ++l) {
+          const int id = s.ids[l];
+          if (id == p.open_id) depth++;
+          else if (id == p.close_id) {
+            if (depth > 0) depth--;
+            else {
+              const int tok = row_argmax(lg + (size_t)l * V, V, lane, paren_excl);
+              __syncthreads();
+              if (lane == 0) s.ids[l] = tok;
+              __syncthreads();
+            }
+          }
+        }
+        depth = 0;
+        for (int l = L - 1; l >= 0; --l) {
+          const int id = s.ids[l];
+          if (id == p.close_id) depth++;
+          else if (id == p.open_id) {
+            if (depth > 0) depth--;
+            else {
+              const int tok = row_argmax(lg + (size_t)l * V, V, lane, paren_excl);
+              __syncthreads();
+              if (lane == 0) s.ids[l] = tok;
+              __syncthreads();
+            }
+          }
+        }
+      }
+      // ---- ring closures: odd count -> replace the last occurrence
+      for (int r = 0; r < p.R; ++r) {
+        const int rid = p.ring_ids[r];
+        int cnt = 0, last = -1;
+        for (int j = 0; j < CH; ++j) {
+          const int l = l0 + j;
+          if (l < L && s.ids[l] == rid) { cnt++; last = l; }
+        }
+        cnt = bd_wave_sum_i(cnt);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(last, o, 64); last = v > last ? v : last; }
+        if (cnt & 1) {
+          const int tok = row_argmax(lg + (size_t)last * V, V, lane, [&](int v) {
+            return (p.tok_flags[v] & BD_TF_RING) != 0 || v == p.mask_id || v == p.pad_id || v == p.bos_id ||
+                   v == p.eos_id || v == p.open_id || v == p.close_id;
+          });
+          __syncthreads();
+          if (lane == 0) s.ids[last] = tok;
+          __syncthreads();
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int l = lane; l < L; l += 64) ids_g[l] = (long long)s.ids[l];
+}
+
+}  // namespace
+
+extern "C" int bd_sample_step(const bd_step_args* a, void* stream) {
+  BD_REQUIRE(a != nullptr, "bd_sample_step: null args");
+  const bd_step_args& p = *a;
+  BD_REQUIRE(p.ids && p.ktable && p.tok_flags && p.contrib && p.ring_slot && p.non_special,
+             "bd_sample_step: null table or ids");
+  BD_REQUIRE(p.B >= 0 && p.L > 0 && p.L <= MAXL, "bd_sample_step: L=%d outside 1..%d", p.L, MAXL);
+  BD_REQUIRE(p.V > 0 && p.V <= MAXV, "bd_sample_step: V=%d outside 1..%d", p.V, MAXV);
+  BD_REQUIRE(p.R >= 0 && p.R <= MAXR, "bd_sample_step: %d ring ids > %d", p.R, MAXR);
+  BD_REQUIRE(p.n_ns > 0, "bd_sample_step: empty fallback token list");
+  BD_REQUIRE(p.temperature > 0.f, "bd_sample_step: temperature must be > 0");
+  BD_REQUIRE(p.t >= 1, "bd_sample_step: t must be >= 1");
+  if (p.hidden != nullptr) {
+    BD_REQUIRE(p.wout != nullptr, "bd_sample_step: hidden mode needs the output projection");
+    BD_REQUIRE(p.d > 0 && p.d <= MAXD && p.d % 8 == 0, "bd_sample_step: d=%d unsupported", p.d);
+  } else {
+    BD_REQUIRE(p.logits != nullptr, "bd_sample_step: neither logits nor hidden states given");
+  }
+  if (p.variant & BD_VB_NATURAL_EOS)
+    BD_REQUIRE(p.has_eos != nullptr, "bd_sample_step: natural-EOS mode needs has_eos");
+  if (p.variant & BD_VB_URGENCY)
+    BD_REQUIRE(p.boost_id >= 0 && p.boost_id < p.V, "bd_sample_step: bad boost id");
+  if (p.B == 0) return BD_OK;
+  hipLaunchKernelGGL(sample_step_kernel, dim3(p.B), dim3(64), 0, (hipStream_t)stream, p);
+  return bd_check_launch("bd_sample_step");
+}
+
+extern "C" int bd_sample_fixup(const bd_fix_args* a, void* stream) {
+  BD_REQUIRE(a != nullptr, "bd_sample_fixup: null args");
+  const bd_fix_args& p = *a;
+  BD_REQUIRE(p.ids, "bd_sample_fixup: null ids");
+  BD_REQUIRE(p.B >= 0 && p.L > 0 && p.L <= MAXL, "bd_sample_fixup: L=%d outside 1..%d", p.L, MAXL);
+  BD_REQUIRE(p.V > 0 && p.V <= MAXV, "bd_sample_fixup: V=%d outside 1..%d", p.V, MAXV);
+  BD_REQUIRE(!p.do_fix || (p.logits && p.count_id >= 0 && p.count_id < p.V),
+             "bd_sample_fixup: repairs need logits and a counted token id");
+  BD_REQUIRE(!p.smiles_syntax || (p.tok_flags && (p.R == 0 || p.ring_ids)),
+             "bd_sample_fixup: SMILES repairs need the token tables");
+  BD_REQUIRE(p.n_excl >= 0 && p.n_excl <= 8, "bd_sample_fixup: too many excluded ids");
+  if (p.B == 0) return BD_OK;
+  hipLaunchKernelGGL(fixup_kernel, dim3(p.B), dim3(64), 0, (hipStream_t)stream, p);
+  return bd_check_launch("bd_sample_fixup");
+}

@@ -1,0 +1,226 @@
+/*
+ * bidiff.h - C ABI of libbidiff_hip.so: the Bi_Diffusion reverse-sampling / training-step
+ * hot path as hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch-ROCm allocates);
+ *     the library keeps no caller pointer after a call returns and allocates nothing
+ *     except where a function says so;
+ *   - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream); calls only
+ *     enqueue work, they never synchronise the device;
+ *   - return value: 0 = ok, negative = error (BD_ERR_*); bd_last_error() gives the text;
+ *   - token ids, attention masks and timesteps are int64, as in the reference's Python API;
+ *     bf16 tensors are passed as void*.
+ *
+ * The reference (htang7415/Discrete-Diffusion-Model-for-inverse-polymer-design) has no
+ * FFI: the interface each entry point stands behind is a Python method, cited per function
+ * as <variant>/src/...py:line (Bi_Diffusion_SMILES unless stated).
+ */
+#ifndef BIDIFF_H
+#define BIDIFF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BD_ERR_ARG (-1)
+#define BD_ERR_LAUNCH (-2)
+#define BD_ERR_UNSUPPORTED (-3)
+
+/* Library identification / diagnostics. */
+const char* bd_version(void);
+const char* bd_last_error(void);
+/* 1 when a HIP device is usable by this process, else 0 (never raises). */
+int bd_device_available(void);
+
+/* ---------------------------------------------------------------- denoiser forward */
+
+/* x[b,l,:] = tok_emb[ids[b,l]] + pos_emb[l] + time_emb[timesteps[b]]   (fp32)
+ * replaces src/model/backbone.py:234-246 (three nn.Embedding lookups and their sum). */
+int bd_embed(const long long* ids, const long long* timesteps, const float* tok_emb,
+             const float* pos_emb, const float* time_emb, float* x, int B, int L, int d,
+             void* stream);
+
+/* LayerNorm over the last dim (eps 1e-5 in the reference), fp32 in; writes bf16 and/or
+ * fp32 output and optionally per-row (mean, rstd) for the backward pass.
+ * replaces nn.LayerNorm at src/model/backbone.py:115,117,194 (calls :126,128,254). */
+int bd_layernorm(const float* x, const float* gamma, const float* beta, void* out_bf16,
+                 float* out_f32, float* stats, int M, int d, float eps, void* stream);
+
+/* C[M,n] = A[M,K] (bf16) * W[n_pad,K]^T (bf16) with a fused epilogue
+ *   0: out bf16 = acc + bias          (q/k/v projections fused as one [3d,d] weight)
+ *   1: out bf16 = gelu_erf(acc + bias)
+ *   2: out fp32 += acc + bias         (residual stream, in place)
+ *   3: out fp32  = acc (+ bias), only columns < n_real are written (vocabulary head)
+ * n_pad % 128 == 0 (weight rows past n_real are zero), K % 64 == 0.
+ * replaces nn.Linear at src/model/backbone.py:49-51,78 (attention), :96-99 (FFN),
+ * :255 (output_proj). */
+int bd_gemm_bf16(const void* A, const void* W, const float* bias, void* out, int M, int n_pad,
+                 int n_real, int K, int ldc, int epilogue, void* stream);
+
+/* Non-causal multi-head attention on the fused qkv rows [B*L, 3*H*head_dim] (bf16) with a
+ * key-padding byte mask [B,L] (non-zero = visible; null = all visible). A query whose keys
+ * are all masked gives an all-zero output row. out [B*L, H*head_dim] bf16; lse optional
+ * [B,H,L] fp32. head_dim in {32, 64, 128}, any L.
+ * replaces F.scaled_dot_product_attention at src/model/backbone.py:54-67. */
+int bd_attention_fwd(const void* qkv, const unsigned char* keymask, void* out, float* lse, int B,
+                     int L, int H, int head_dim, void* stream);
+
+/* out[i] = attention_mask[i] != 0 (the .to(torch.bool) of src/model/backbone.py:59). */
+int bd_mask_to_bytes(const long long* attention_mask, unsigned char* out, long long n, void* stream);
+
+/* Weights of one pre-LN transformer block (device pointers; bf16 matrices are row-major
+ * [out, in] exactly as torch.nn.Linear stores them, q/k/v stacked into one [3d, d]). */
+typedef struct bd_layer_weights {
+  const float* ln1_g; const float* ln1_b;
+  const void* w_qkv;  const float* b_qkv;   /* [3d, d] bf16, [3d] fp32 */
+  const void* w_o;    const float* b_o;     /* [d, d],  [d]            */
+  const float* ln2_g; const float* ln2_b;
+  const void* w_fc1;  const float* b_fc1;   /* [F, d],  [F]            */
+  const void* w_fc2;  const float* b_fc2;   /* [d, F],  [d]            */
+} bd_layer_weights;
+
+typedef struct bd_backbone_desc {
+  int d, n_layers, n_heads, ffn, vocab, vocab_pad, max_pos, n_timesteps;
+  float ln_eps;
+  const float* tok_emb;   /* [vocab, d]        fp32 */
+  const float* pos_emb;   /* [max_pos, d]      fp32 */
+  const float* time_emb;  /* [n_timesteps, d]  fp32 */
+  const float* lnf_g; const float* lnf_b;
+  const void* w_out;      /* [vocab_pad, d] bf16, rows >= vocab are zero */
+  const bd_layer_weights* layers; /* HOST array of n_layers entries */
+} bd_backbone_desc;
+
+/* Bytes of device scratch bd_backbone_forward needs for a [B, L] batch. */
+long long bd_backbone_workspace_bytes(const bd_backbone_desc* desc, int B, int L);
+
+/* Whole denoiser forward (inference, no dropout): embeddings -> n_layers x
+ * [LN -> QKV -> attention -> out-proj + residual -> LN -> fc1 + GELU -> fc2 + residual]
+ * -> final LN (-> vocabulary projection). Writes hidden_out [B*L, d] bf16 (final-norm
+ * output; may be null) and/or logits_out [B*L, vocab] fp32 (may be null). keymask: byte
+ * mask [B, L] or null. workspace: caller-allocated device scratch.
+ * replaces DiffusionBackbone.forward, src/model/backbone.py:215-257 (hidden_out with
+ * logits_out == null: get_hidden_states(layer_idx=-1), :259-299). */
+int bd_backbone_forward(const bd_backbone_desc* desc, const long long* ids,
+                        const long long* timesteps, const unsigned char* keymask, int B, int L,
+                        void* workspace, long long workspace_bytes, void* hidden_out,
+                        float* logits_out, void* stream);
+
+/* ---------------------------------------------------------------- q(x_t | x_0) */
+
+/* should_mask = (u < schedule[t[b]]) & (attention_mask == 1, or ids != pad when the mask is
+ * null) & ids != bos & ids != eos (bos/eos < 0 = "None"); noisy = mask_id where should_mask.
+ * uniforms [B,L] fp32 or null; null draws u from Philox4x32-10 keyed by
+ * (seed, seq_offset + b, t[b], l).
+ * replaces DiscreteMaskingDiffusion.forward_process, src/model/diffusion.py:84-127. */
+int bd_corrupt(const long long* ids, const long long* attention_mask, const long long* timesteps,
+               const float* schedule, int schedule_len, const float* uniforms,
+               long long* noisy_ids, unsigned char* mask_indicator, int B, int L, int mask_id,
+               int pad_id, int bos_id, int eos_id, unsigned long long seed, long long seq_offset,
+               void* stream);
+
+/* ---------------------------------------------------------------- reverse step */
+
+#define BD_SAMPLE_MAX_L 512
+#define BD_SAMPLE_MAX_V 1024
+#define BD_SAMPLE_MAX_D 2048
+#define BD_SAMPLE_MAX_RING 128
+
+/* token class bits, tok_flags[v] */
+#define BD_TF_BOND 1      /* - = # / \                                  */
+#define BD_TF_RING 2      /* ring digit or %nn                          */
+#define BD_TF_OPEN 4      /* (                                          */
+#define BD_TF_CLOSE 8     /* )                                          */
+#define BD_TF_SPECIAL 16  /* always forbidden at MASK positions         */
+#define BD_TF_COUNTED 32  /* star / placeholder-bearing token           */
+#define BD_TF_EOS 64      /* EOS (forbidden unless natural-EOS mode lets it through) */
+
+/* sampler variant bits */
+#define BD_VB_FIXED 1        /* honour fixed_mask when choosing positions (SMILES / BPE)   */
+#define BD_VB_SYNTAX 2       /* SMILES parenthesis / ring / bond constraints               */
+#define BD_VB_URGENCY 4      /* SELFIES placeholder urgency boost                          */
+#define BD_VB_SORTED 8       /* draw the chosen positions left to right (SELFIES)          */
+#define BD_VB_NATURAL_EOS 16 /* SELFIES allow_natural_eos=True                              */
+
+typedef struct bd_step_args {
+  long long* ids;               /* [B,L] in/out                                             */
+  const unsigned char* fixed;   /* [B,L] fixed_mask bytes or null                           */
+  long long* attn;              /* [B,L] in/out, touched only in natural-EOS mode, or null  */
+  unsigned char* keymask;       /* [B,L] byte mirror of attn, same rule, or null            */
+  unsigned char* has_eos;       /* [B] in/out, natural-EOS mode only                        */
+  float* logits;                /* LOGITS mode: [B,L,V] raw logits in, edited logits out.
+                                   HIDDEN mode: optional [B,L,V] dump of the raw rows used  */
+  const void* hidden;           /* HIDDEN mode: [B,L,d] bf16 final-norm output, else null   */
+  const void* wout;             /* HIDDEN mode: [>=V,d] bf16 output projection              */
+  const float* u_sel;           /* [B,L] selection keys or null (Philox)                    */
+  const float* u_tok;           /* [B,L,V] token uniforms or null (Philox)                  */
+  const int* ktable;            /* [L+1]: max(1, int(n * (1.0 / t))) for n = 0..L           */
+  const unsigned char* tok_flags; /* [V]                                                    */
+  const int* contrib;           /* [V] star / placeholder contribution of each token        */
+  const int* ring_slot;         /* [V] index into the ring-id list or -1                    */
+  const int* counted_ids;       /* [n_counted] tokens with contrib > 0                      */
+  const int* bond_ids;          /* [n_bond]                                                 */
+  const int* non_special;       /* [n_ns] fallback pool                                     */
+  int n_counted, n_bond, n_ns, R;
+  int B, L, V, d;
+  int mask_id, pad_id, bos_id, eos_id, open_id, close_id, boost_id;
+  int variant, use_constraints, t;
+  float temperature;
+  unsigned long long seed;
+  long long seq_offset;
+} bd_step_args;
+
+/* One reverse step t for a batch: static constraints, choice of k positions per sequence,
+ * sequential Gumbel-max draws with in-step constraint updates, ids updated in place.
+ * replaces the body of the `for t in steps` loop after the backbone call:
+ * src/sampling/sampler.py:667-718 (SMILES / SMILES_BPE),
+ * Bi_Diffusion_SELFIES/src/sampling/sampler.py:306-393,
+ * Bi_Diffusion_Group_SELFIES/src/sampling/sampler.py:363-418. */
+int bd_sample_step(const bd_step_args* args, void* stream);
+
+typedef struct bd_fix_args {
+  long long* ids;               /* [B,L] in/out                                             */
+  const float* logits;          /* [B,L,V] final logits (after the t = 1 step's edits)      */
+  long long* attn;              /* natural-EOS finalisation only, or null                   */
+  unsigned char* keymask;       /* same                                                      */
+  unsigned char* has_eos;       /* same                                                      */
+  const unsigned char* tok_flags; /* [V] (SMILES repairs)                                   */
+  const int* ring_ids;          /* [R]                                                       */
+  int excl[8];                  /* ids excluded (besides count_id) when replacing an extra  */
+  int n_excl, R;
+  int B, L, V;
+  int mask_id, pad_id, bos_id, eos_id, open_id, close_id;
+  int count_id, target;         /* star / placeholder id and the wanted count (2)           */
+  int do_fix, smiles_syntax, natural_eos;
+} bd_fix_args;
+
+/* Post-loop repairs: natural-EOS completion, star / placeholder count, parenthesis balance,
+ * ring-closure pairing.
+ * replaces src/sampling/sampler.py:447-632 (called :720-723),
+ * Bi_Diffusion_SELFIES/src/sampling/sampler.py:156-220, 395-414,
+ * Bi_Diffusion_Group_SELFIES/src/sampling/sampler.py:247-315. */
+int bd_sample_fixup(const bd_fix_args* args, void* stream);
+
+/* Host-side evaluation of the device uniform / Gumbel functions (testing aid; the product
+ * never needs it): out[i] = gumbel(u[i]); Philox words for a counter/key. */
+void bd_host_gumbel(const float* u, float* out, long long n);
+void bd_host_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                    uint32_t out[4]);
+float bd_host_uniform_select(unsigned long long seed, uint32_t seq, uint32_t t, uint32_t pos);
+float bd_host_uniform_token(unsigned long long seed, uint32_t seq, uint32_t t, uint32_t pos,
+                            uint32_t v);
+
+/* ---------------------------------------------------------------- event profiling */
+
+/* When enabled, every bd_gemm_bf16 launch is bracketed by HIP events on its stream so that
+ * bench.py can report the kernel's average duration. bd_prof_read synchronises the recorded
+ * events and returns launches / total milliseconds / total flops since the last reset. */
+int bd_prof_enable(int on);
+int bd_prof_read(long long* launches, double* total_ms, double* total_flops, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIDIFF_H */

@@ -1,0 +1,81 @@
+"""TEST INFRASTRUCTURE - fp32 PyTorch restatement of the denoiser forward and the loss.
+
+Functional (takes a state_dict with the reference's key names), CPU or any torch device.
+Follows Bi_Diffusion_SMILES/src/model/backbone.py:
+  embeddings :234-247, block :120-129, attention :46-78 (SDPA with a boolean key mask,
+  a fully masked query row gives an all-zero attention output), FFN :95-101 (erf GELU),
+  final norm + vocabulary projection :254-255;
+and Bi_Diffusion_SMILES/src/model/diffusion.py: schedule :60-71, loss :169-209.
+Dropout is the identity (eval mode / dropout=0).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def attention(x, sd, prefix, num_heads, attention_mask):
+    B, L, d = x.shape
+    dh = d // num_heads
+
+    def proj(name):
+        return F.linear(x, sd[f"{prefix}.{name}.weight"], sd[f"{prefix}.{name}.bias"])
+    q = proj("q_proj").view(B, L, num_heads, dh).transpose(1, 2)
+    k = proj("k_proj").view(B, L, num_heads, dh).transpose(1, 2)
+    v = proj("v_proj").view(B, L, num_heads, dh).transpose(1, 2)
+    scores = torch.matmul(q, k.transpose(-2, -1)) * (1.0 / math.sqrt(dh))
+    if attention_mask is not None:
+        vis = attention_mask.to(torch.bool)[:, None, None, :]
+        scores = scores.masked_fill(~vis, float("-inf"))
+    probs = torch.softmax(scores, dim=-1)
+    probs = torch.nan_to_num(probs, nan=0.0)      # all keys masked -> zero output row
+    out = torch.matmul(probs, v).transpose(1, 2).contiguous().view(B, L, d)
+    return F.linear(out, sd[f"{prefix}.out_proj.weight"], sd[f"{prefix}.out_proj.bias"])
+
+
+def hidden_states(sd, cfg, input_ids, timesteps, attention_mask=None, prefix="", eps=1e-5):
+    """Final-norm hidden states [B, L, d] (fp32)."""
+    p = prefix
+    B, L = input_ids.shape
+    d = cfg["hidden_size"]
+    if timesteps.dim() == 2:
+        timesteps = timesteps.squeeze(-1)
+    pos = torch.arange(L, device=input_ids.device)
+    x = (sd[p + "token_embedding.weight"][input_ids] + sd[p + "position_embedding.weight"][pos][None]
+         + sd[p + "timestep_embedding.weight"][timesteps][:, None, :])
+    for i in range(cfg["num_layers"]):
+        lp = f"{p}layers.{i}"
+        h = F.layer_norm(x, (d,), sd[f"{lp}.norm1.weight"], sd[f"{lp}.norm1.bias"], eps)
+        x = x + attention(h, sd, f"{lp}.attn", cfg["num_heads"], attention_mask)
+        h = F.layer_norm(x, (d,), sd[f"{lp}.norm2.weight"], sd[f"{lp}.norm2.bias"], eps)
+        h = F.linear(h, sd[f"{lp}.ffn.fc1.weight"], sd[f"{lp}.ffn.fc1.bias"])
+        h = F.gelu(h)
+        x = x + F.linear(h, sd[f"{lp}.ffn.fc2.weight"], sd[f"{lp}.ffn.fc2.bias"])
+    return F.layer_norm(x, (d,), sd[p + "final_norm.weight"], sd[p + "final_norm.bias"], eps)
+
+
+def logits(sd, cfg, input_ids, timesteps, attention_mask=None, prefix=""):
+    h = hidden_states(sd, cfg, input_ids, timesteps, attention_mask, prefix)
+    return F.linear(h, sd[prefix + "output_proj.weight"])
+
+
+def mask_schedule(num_steps, beta_min=0.05, beta_max=0.95, force_clean_t0=False):
+    """fp32 evaluation in the reference's operand order (diffusion.py:67-70)."""
+    steps = torch.arange(num_steps + 1, dtype=torch.float32)
+    s = beta_min + (beta_max - beta_min) * steps / num_steps
+    if force_clean_t0:
+        s[0] = 0.0
+    return s
+
+
+def masked_ce(logits_t, targets, mask_indicator, attention_mask=None):
+    """Mean CE over masked & non-pad positions; exactly 0 when there is none (diffusion.py:187-209)."""
+    V = logits_t.shape[-1]
+    ce = F.cross_entropy(logits_t.reshape(-1, V).float(), targets.reshape(-1), reduction="none").view_as(targets)
+    valid = mask_indicator.float()
+    if attention_mask is not None:
+        valid = valid * attention_mask.float()
+    cnt = valid.sum()
+    if cnt.item() == 0:
+        return logits_t.sum() * 0.0
+    return (ce * valid).sum() / cnt

@@ -1,0 +1,123 @@
+"""Deterministic inputs shared by the fixture generators and the tests that replay them.
+
+All arrays come from ``numpy.random.RandomState`` (legacy MT19937 stream, frozen by NumPy's
+compatibility policy), so a fixture only has to store seeds and expected outputs.
+"""
+import numpy as np
+
+from bidiff.utils import synthetic
+
+_SM = synthetic.smiles_vocab()
+_SF = synthetic.selfies_vocab()
+_GR, _ = synthetic.group_selfies_vocab()
+
+
+def _b(vocab, **kw):
+    return {vocab[k]: v for k, v in kw.items()}
+
+
+def _smiles_bias(scale_syntax=2.5):
+    s = scale_syntax
+    return {_SM["("]: s, _SM[")"]: s, _SM["*"]: s, _SM["-"]: s * 0.6, _SM["="]: s, _SM["#"]: s * 0.5,
+            _SM["1"]: s, _SM["2"]: s * 0.8, _SM["%10"]: s * 0.5, _SM["[EOS]"]: 1.0, _SM["[PAD]"]: 1.0}
+
+
+CASES = {
+    "smiles": {
+        "on_small": dict(kind="sample", B=8, L=24, T=12, temperature=1.0, use_constraints=True, seed=101,
+                         scale=2.0, bias=_smiles_bias()),
+        "off_temp": dict(kind="sample", B=6, L=20, T=9, temperature=0.7, use_constraints=False, seed=102,
+                         scale=2.0, bias=_smiles_bias()),
+        "lengths": dict(kind="lengths", B=6, L=24, T=8, temperature=1.3, use_constraints=True, seed=103,
+                        scale=2.0, bias=_smiles_bias(), lengths=[5, 9, 24, 2, 17, 12]),
+        "conditional": dict(kind="conditional", B=4, L=16, T=6, temperature=1.0, use_constraints=True, seed=104,
+                            scale=2.0, bias=_smiles_bias(), prefix=[_SM["C"], _SM["("]], suffix=[_SM[")"]]),
+        "long70": dict(kind="sample", B=3, L=70, T=5, temperature=1.0, use_constraints=True, seed=105,
+                       scale=2.0, bias=_smiles_bias(2.0)),
+        "long130": dict(kind="sample", B=2, L=130, T=4, temperature=0.9, use_constraints=True, seed=106,
+                        scale=1.5, bias=_smiles_bias(3.0)),
+        # only parentheses are finite: rows where both are forbidden take the fallback pool
+        "fallback": dict(kind="sample", B=5, L=14, T=7, temperature=1.0, use_constraints=True, seed=107,
+                         scale=1.0, bias={}, only=[_SM["("], _SM[")"]], tie_hazard=True),
+        "t49": dict(kind="sample", B=2, L=100, T=49, temperature=1.0, use_constraints=True, seed=108,
+                    scale=2.0, bias=_smiles_bias()),
+    },
+    "selfies": {
+        "on_small": dict(kind="sample", B=8, L=20, T=10, temperature=1.0, use_constraints=True, seed=201,
+                         scale=2.0, bias={_SF["[I+3]"]: 1.0}),
+        "on_rare_ph": dict(kind="sample", B=8, L=18, T=9, temperature=1.0, use_constraints=True, seed=202,
+                           scale=1.0, bias={_SF["[I+3]"]: -6.0}),
+        "natural_eos": dict(kind="sample", B=8, L=22, T=8, temperature=1.1, use_constraints=True, seed=203,
+                            scale=2.0, bias={_SF["[I+3]"]: 0.5, _SF["[EOS]"]: 2.5}, natural_eos=True),
+        "off": dict(kind="sample", B=5, L=16, T=6, temperature=0.8, use_constraints=False, seed=204,
+                    scale=2.0, bias={_SF["[I+3]"]: 2.0}),
+        "long70": dict(kind="sample", B=3, L=70, T=5, temperature=1.0, use_constraints=True, seed=205,
+                       scale=2.0, bias={_SF["[I+3]"]: -2.0}),
+    },
+    "group": {
+        "on_small": dict(kind="sample", B=8, L=20, T=10, temperature=1.0, use_constraints=True, seed=301,
+                         scale=2.0, bias={_GR["[IH0+3]"]: 3.0, _GR["[:/0G0]"]: 3.0, _GR["[:/0G4]"]: 3.0,
+                                          _GR["[UNK]"]: 4.0}),
+        "off": dict(kind="sample", B=5, L=16, T=6, temperature=1.2, use_constraints=False, seed=302,
+                    scale=2.0, bias={_GR["[IH0+3]"]: 3.0, _GR["[:/0G4]"]: 3.0}),
+        "long70": dict(kind="sample", B=3, L=70, T=5, temperature=1.0, use_constraints=True, seed=303,
+                       scale=2.0, bias={_GR["[IH0+3]"]: 2.0, _GR["[:/0G1]"]: 2.0}),
+    },
+}
+
+
+def step_logits(case, t, B, L, V):
+    rs = np.random.RandomState(case["seed"] * 1000 + t)
+    x = rs.standard_normal((B, L, V)) * case["scale"]
+    for tok, bias in case.get("bias", {}).items():
+        x[:, :, tok] += bias
+    x = x.astype(np.float32)
+    if case.get("only"):
+        keep = np.zeros(V, dtype=bool)
+        keep[list(case["only"])] = True
+        x[:, :, ~keep] = -np.inf
+    return x
+
+
+def step_u_sel(case, t, B, L):
+    rs = np.random.RandomState(case["seed"] * 1000 + 500 + t)
+    return rs.random_sample((B, L)).astype(np.float32)
+
+
+def step_u_tok(case, t, B, L, V):
+    rs = np.random.RandomState(case["seed"] * 1000 + 700 + t)
+    return rs.random_sample((B, L, V)).astype(np.float32)
+
+
+def _neglog_np(x):
+    """-ln(x) with fp32 multiplies/adds only: the numpy twin of the library's bd_neglog."""
+    x = np.asarray(x, dtype=np.float32)
+    bits = x.view(np.uint32)
+    e = (bits >> np.uint32(23)).astype(np.int32) - 127
+    m = ((bits & np.uint32(0x007FFFFF)) | np.uint32(0x3F800000)).view(np.float32)
+    big = m > np.float32(1.41421356)
+    m = np.where(big, m * np.float32(0.5), m).astype(np.float32)
+    e = np.where(big, e + 1, e)
+    f = (m - np.float32(1.0)).astype(np.float32)
+    z = (f * f).astype(np.float32)
+    y = np.full_like(f, np.float32(7.0376836292e-2))
+    for c in (-1.1514610310e-1, 1.1676998740e-1, -1.2420140846e-1, 1.4249322787e-1, -1.6668057665e-1,
+              2.0000714765e-1, -2.4999993993e-1, 3.3333331174e-1):
+        y = (y * f).astype(np.float32)
+        y = (y + np.float32(c)).astype(np.float32)
+    y = (y * f).astype(np.float32)
+    y = (y * z).astype(np.float32)
+    hz = (np.float32(0.5) * z).astype(np.float32)
+    y = (y - hz).astype(np.float32)
+    r = (f + y).astype(np.float32)
+    el = (e.astype(np.float32) * np.float32(0.693147180559945)).astype(np.float32)
+    r = (r + el).astype(np.float32)
+    return (-r).astype(np.float32)
+
+
+def gumbel_np(u):
+    u = np.array(u, dtype=np.float32, copy=True)
+    lo = np.float32(2.98023223876953125e-08)
+    u = np.where(u > lo, u, lo).astype(np.float32)
+    u = np.minimum(u, np.float32(0.99999994)).astype(np.float32)
+    return _neglog_np(_neglog_np(u))
