@@ -121,3 +121,51 @@ def gumbel_np(u):
     u = np.where(u > lo, u, lo).astype(np.float32)
     u = np.minimum(u, np.float32(0.99999994)).astype(np.float32)
     return _neglog_np(_neglog_np(u))
+
+
+# ---------------------------------------------------------------- denoiser fixtures
+BACKBONE_CFGS = {
+    "tiny_h2": dict(vocab_size=39, hidden_size=128, num_layers=2, num_heads=2, ffn_hidden_size=256,
+                    max_position_embeddings=64, num_diffusion_steps=20, dropout=0.0, pad_token_id=0),
+    "tiny_h1": dict(vocab_size=39, hidden_size=128, num_layers=2, num_heads=1, ffn_hidden_size=256,
+                    max_position_embeddings=64, num_diffusion_steps=20, dropout=0.0, pad_token_id=0),
+    "tiny_h4": dict(vocab_size=43, hidden_size=128, num_layers=1, num_heads=4, ffn_hidden_size=128,
+                    max_position_embeddings=160, num_diffusion_steps=10, dropout=0.0, pad_token_id=0),
+}
+SMALL_CFG = dict(vocab_size=39, hidden_size=384, num_layers=6, num_heads=3, ffn_hidden_size=1536,
+                 max_position_embeddings=256, num_diffusion_steps=100, dropout=0.1, pad_token_id=0)
+
+
+def perturb_state_dict(sd, seed):
+    """Make biases and LayerNorm affine parameters non-trivial (the seeded init leaves them at
+    0 / 1): in-place, key order of the state_dict, frozen RandomState stream."""
+    import torch
+    rs = np.random.RandomState(seed)
+    for k, v in sd.items():
+        if not v.dtype.is_floating_point or k.endswith("mask_schedule"):
+            continue
+        noise = torch.from_numpy(rs.standard_normal(tuple(v.shape)).astype(np.float32))
+        if k.endswith("bias"):
+            v.add_(0.1 * noise)
+        elif "norm" in k and k.endswith("weight"):
+            v.add_(0.1 * noise)
+        else:
+            v.add_(0.02 * noise)
+    return sd
+
+
+def backbone_inputs(cfg, seed, B=5, L=24):
+    rs = np.random.RandomState(seed)
+    ids = rs.randint(5, cfg["vocab_size"], size=(B, L)).astype(np.int64)
+    lengths = [L, 10, 1, 0, 17][:B] + [L] * max(0, B - 5)
+    attn = np.zeros((B, L), dtype=np.int64)
+    for b, n in enumerate(lengths):
+        attn[b, :n] = 1
+        ids[b, n:] = 0
+        if n >= 1:
+            ids[b, 0] = 2
+        if n >= 2:
+            ids[b, n - 1] = 3
+    ids[0, 3:9] = 1
+    t = rs.randint(1, cfg["num_diffusion_steps"] + 1, size=(B,)).astype(np.int64)
+    return ids, attn, t

@@ -97,3 +97,77 @@ def oracle_replay(variant, case, golden):
     fix = ora.sample_fixup(tb, ids, last_logits, do_fix=case["use_constraints"], natural_eos=natural,
                            attn=attn if natural else None, has_eos=has_eos if natural else None)
     return per_step, fix["ids"], last_logits
+
+
+# ---------------------------------------------------------------- HIP step / fixup through the C ABI
+def hip_tables(tb, device):
+    import torch
+
+    def up(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    return {k: up(getattr(tb, k)) for k in ("tok_flags", "contrib", "ring_slot", "counted_ids", "bond_ids",
+                                            "non_special", "ring_ids")}
+
+
+def hip_step(tb, dt, ids, ktable_row, t, logits=None, hidden=None, wout=None, dump=None, temperature=1.0,
+             use_constraints=True, fixed=None, u_sel=None, u_tok=None, seed=0, seq_offset=0, natural_eos=False,
+             attn=None, keymask=None, has_eos=None):
+    """Call bd_sample_step on device tensors (mutated in place)."""
+    import ctypes as C
+    import torch
+    from bidiff import _lib
+    a = _lib.StepArgs()
+    B, L = ids.shape
+    a.ids = ids.data_ptr()
+    a.fixed = None if fixed is None else fixed.data_ptr()
+    a.attn = None if attn is None else attn.data_ptr()
+    a.keymask = None if keymask is None else keymask.data_ptr()
+    a.has_eos = None if has_eos is None else has_eos.data_ptr()
+    if hidden is not None:
+        a.hidden, a.wout = hidden.data_ptr(), wout.data_ptr()
+        a.logits = None if dump is None else dump.data_ptr()
+        a.d = hidden.shape[-1]
+    else:
+        a.hidden, a.wout, a.logits, a.d = None, None, logits.data_ptr(), 0
+    a.u_sel = None if u_sel is None else u_sel.data_ptr()
+    a.u_tok = None if u_tok is None else u_tok.data_ptr()
+    kt = torch.as_tensor(np.ascontiguousarray(ktable_row, dtype=np.int32)).to(ids.device)
+    a.ktable = kt.data_ptr()
+    a.tok_flags, a.contrib, a.ring_slot = dt["tok_flags"].data_ptr(), dt["contrib"].data_ptr(), dt["ring_slot"].data_ptr()
+    a.counted_ids, a.bond_ids, a.non_special = dt["counted_ids"].data_ptr(), dt["bond_ids"].data_ptr(), dt["non_special"].data_ptr()
+    a.n_counted, a.n_bond, a.n_ns, a.R = len(tb.counted_list), len(tb.bond_ids_list), len(tb.non_special_list), len(tb.ring_ids_list)
+    a.B, a.L, a.V = B, L, tb.V
+    a.mask_id, a.pad_id, a.bos_id, a.eos_id = tb.mask_id, tb.pad_id, tb.bos_id, tb.eos_id
+    a.open_id, a.close_id, a.boost_id = tb.open_id, tb.close_id, tb.boost_id
+    a.variant = tb.variant | (16 if natural_eos else 0)
+    a.use_constraints, a.t = int(use_constraints), int(t)
+    a.temperature = float(temperature)
+    a.seed, a.seq_offset = int(seed), int(seq_offset)
+    _lib.check(_lib.lib().bd_sample_step(C.byref(a), _lib.stream_handle()), "bd_sample_step")
+    torch.cuda.synchronize()
+
+
+def hip_fixup(tb, dt, ids, logits, do_fix=True, natural_eos=False, attn=None, keymask=None, has_eos=None):
+    import ctypes as C
+    import torch
+    from bidiff import _lib
+    f = _lib.FixArgs()
+    B, L = ids.shape
+    f.ids = ids.data_ptr()
+    f.logits = None if logits is None else logits.data_ptr()
+    f.attn = None if attn is None else attn.data_ptr()
+    f.keymask = None if keymask is None else keymask.data_ptr()
+    f.has_eos = None if has_eos is None else has_eos.data_ptr()
+    f.tok_flags, f.ring_ids = dt["tok_flags"].data_ptr(), dt["ring_ids"].data_ptr()
+    for i, v in enumerate(tb.fix_excl[:8]):
+        f.excl[i] = int(v)
+    f.n_excl, f.R = len(tb.fix_excl[:8]), len(tb.ring_ids_list)
+    f.B, f.L, f.V = B, L, tb.V
+    f.mask_id, f.pad_id, f.bos_id, f.eos_id = tb.mask_id, tb.pad_id, tb.bos_id, tb.eos_id
+    f.open_id, f.close_id = tb.open_id, tb.close_id
+    f.count_id, f.target = tb.count_id, 2
+    f.do_fix = int(do_fix and logits is not None and tb.count_id >= 0)
+    f.smiles_syntax = int(bool(f.do_fix) and tb.fix_syntax)
+    f.natural_eos = int(natural_eos)
+    _lib.check(_lib.lib().bd_sample_fixup(C.byref(f), _lib.stream_handle()), "bd_sample_fixup")
+    torch.cuda.synchronize()

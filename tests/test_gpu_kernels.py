@@ -1,0 +1,171 @@
+"""GPU parity of the individual HIP kernels, called through the C ABI, against fp32 PyTorch
+references on the same (bf16-rounded) inputs."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+from bidiff import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _s():
+    return _lib.stream_handle()
+
+
+def gemm(A, W, bias, out, n_real, epi):
+    M, K = A.shape
+    rc = _lib.lib().bd_gemm_bf16(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(out), M, W.shape[0], n_real, K,
+                                 out.shape[1], epi, _s())
+    _lib.check(rc, "gemm")
+    torch.cuda.synchronize()
+
+
+def test_gemm_layout_exact_integers(gpu_device):
+    """Small-integer operands make every product exact: any fragment / permutation mistake shows
+    as a hard mismatch (asymmetric operands, A != identity)."""
+    dev = gpu_device
+    M, N, K = 200, 256, 128
+    g = torch.Generator().manual_seed(0)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    W = torch.randint(-3, 4, (N, K), generator=g).float()
+    bias = torch.randint(-5, 6, (N,), generator=g).float()
+    ref = A @ W.t() + bias
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    gemm(A.to(dev).bfloat16(), W.to(dev).bfloat16(), bias.to(dev), out, N, 0)
+    assert torch.equal(out.float().cpu(), ref.bfloat16().float())
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 384, 384), (1000, 1152, 384), (257, 384, 1536),
+                                   (64, 1536, 384), (4096, 384, 384)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_epilogues(gpu_device, M, N, K, epi):
+    dev = gpu_device
+    g = torch.Generator().manual_seed(M + N + K + epi)
+    A = (torch.randn(M, K, generator=g) * 0.7).bfloat16()
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16()
+    bias = torch.randn(N, generator=g) * 0.3
+    acc = A.float() @ W.float().t() + bias
+    if epi == 0:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        ref = acc
+    elif epi == 1:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        ref = torch.nn.functional.gelu(acc)
+    else:
+        x0 = torch.randn(M, N, generator=g)
+        out = x0.clone().to(dev)
+        ref = x0 + acc
+    gemm(A.to(dev), W.to(dev), bias.to(dev), out, N, epi)
+    got = out.float().cpu()
+    tol = 2e-2 if epi != 2 else 1e-4
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < tol, err
+
+
+@pytest.mark.parametrize("V", [39, 43, 233, 803])
+def test_gemm_ragged_vocab_head(gpu_device, V):
+    dev = gpu_device
+    M, K = 333, 384
+    g = torch.Generator().manual_seed(V)
+    A = torch.randn(M, K, generator=g).bfloat16()
+    Wr = (torch.randn(V, K, generator=g) / math.sqrt(K)).bfloat16()
+    vpad = (V + 127) // 128 * 128
+    W = torch.zeros(vpad, K, dtype=torch.bfloat16)
+    W[:V] = Wr
+    out = torch.full((M, V), float("nan"), device=dev)
+    gemm(A.to(dev), W.to(dev), None, out, V, 3)
+    ref = A.float() @ Wr.float().t()
+    got = out.cpu()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() / ref.abs().max().item() < 1e-4
+
+
+def ref_attention(qkv, mask, B, L, Hh, dh):
+    d = Hh * dh
+    x = qkv.float().view(B, L, 3, Hh, dh)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+    s = q @ k.transpose(-1, -2) / math.sqrt(dh)
+    if mask is not None:
+        s = s.masked_fill(~mask.bool()[:, None, None, :], float("-inf"))
+    p = torch.nan_to_num(torch.softmax(s, dim=-1), nan=0.0)
+    return (p @ v).transpose(1, 2).reshape(B * L, d)
+
+
+@pytest.mark.parametrize("dh,Hh", [(32, 4), (64, 2), (64, 6), (128, 1), (128, 3)])
+@pytest.mark.parametrize("L", [24, 128, 150, 512])
+def test_attention_key_padding(gpu_device, dh, Hh, L):
+    dev = gpu_device
+    B = 5
+    d = Hh * dh
+    g = torch.Generator().manual_seed(dh * 1000 + L)
+    qkv = torch.randn(B * L, 3 * d, generator=g).bfloat16()
+    lengths = [L, max(1, L // 3), 1, 0, L - 5]
+    mask = torch.zeros(B, L, dtype=torch.uint8)
+    for b, n in enumerate(lengths):
+        mask[b, :n] = 1
+    mask[4, 2] = 0  # a hole in the middle
+    out = torch.full((B * L, d), float("nan"), dtype=torch.bfloat16, device=dev)
+    rc = _lib.lib().bd_attention_fwd(_lib.ptr(qkv.to(dev)), _lib.ptr(mask.to(dev)), _lib.ptr(out), None, B, L, Hh,
+                                     dh, _s())
+    _lib.check(rc, "attention")
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    ref = ref_attention(qkv, mask, B, L, Hh, dh)
+    assert torch.isfinite(got).all()
+    assert got.view(B, L, d)[3].abs().max().item() == 0.0, "fully padded sequence must give exact zeros"
+    assert (got - ref).abs().max().item() < 2e-2
+    # no mask at all
+    rc = _lib.lib().bd_attention_fwd(_lib.ptr(qkv.to(dev)), None, _lib.ptr(out), None, B, L, Hh, dh, _s())
+    _lib.check(rc, "attention")
+    torch.cuda.synchronize()
+    assert (out.float().cpu() - ref_attention(qkv, None, B, L, Hh, dh)).abs().max().item() < 2e-2
+
+
+@pytest.mark.parametrize("M,d", [(7, 128), (1000, 384), (513, 768), (64, 1024), (33, 2048)])
+def test_layernorm(gpu_device, M, d):
+    dev = gpu_device
+    g = torch.Generator().manual_seed(d + M)
+    x = torch.randn(M, d, generator=g) * 3 + 1.5
+    gm = torch.randn(d, generator=g)
+    bt = torch.randn(d, generator=g)
+    ob = torch.empty(M, d, dtype=torch.bfloat16, device=dev)
+    of = torch.empty(M, d, device=dev)
+    st = torch.empty(M, 2, device=dev)
+    rc = _lib.lib().bd_layernorm(_lib.ptr(x.to(dev)), _lib.ptr(gm.to(dev)), _lib.ptr(bt.to(dev)), _lib.ptr(ob),
+                                 _lib.ptr(of), _lib.ptr(st), M, d, 1e-5, _s())
+    _lib.check(rc, "layernorm")
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.layer_norm(x, (d,), gm, bt, 1e-5)
+    assert (of.cpu() - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+    assert (ob.float().cpu() - ref).abs().max().item() < 2e-2 * ref.abs().max().item()
+    assert (st[:, 0].cpu() - x.mean(1)).abs().max().item() < 1e-5
+
+
+def test_embed(gpu_device):
+    dev = gpu_device
+    B, L, d, V, T = 4, 10, 128, 39, 21
+    g = torch.Generator().manual_seed(1)
+    tok, pos, tim = torch.randn(V, d, generator=g), torch.randn(64, d, generator=g), torch.randn(T, d, generator=g)
+    ids = torch.randint(0, V, (B, L), generator=g)
+    t = torch.randint(0, T, (B,), generator=g)
+    x = torch.empty(B * L, d, device=dev)
+    rc = _lib.lib().bd_embed(_lib.ptr(ids.to(dev)), _lib.ptr(t.to(dev)), _lib.ptr(tok.to(dev)), _lib.ptr(pos.to(dev)),
+                             _lib.ptr(tim.to(dev)), _lib.ptr(x), B, L, d, _s())
+    _lib.check(rc, "embed")
+    torch.cuda.synchronize()
+    ref = tok[ids] + pos[:L][None] + tim[t][:, None]
+    assert torch.equal(x.cpu().view(B, L, d), ref)
+
+
+def test_bad_arguments_are_rejected(gpu_device):
+    lib = _lib.lib()
+    a = torch.zeros(8, 64, dtype=torch.bfloat16, device=gpu_device)
+    assert lib.bd_gemm_bf16(_lib.ptr(a), _lib.ptr(a), None, _lib.ptr(a), 8, 100, 100, 64, 100, 0, _s()) < 0
+    assert b"multiple" in lib.bd_last_error()
+    assert lib.bd_attention_fwd(_lib.ptr(a), None, _lib.ptr(a), None, 1, 8, 1, 48, _s()) < 0
+    assert lib.bd_gemm_bf16(None, _lib.ptr(a), None, _lib.ptr(a), 8, 128, 128, 64, 128, 0, _s()) < 0

@@ -1,0 +1,127 @@
+"""GPU parity of the product modules (DiffusionBackbone / DiscreteMaskingDiffusion on the HIP
+library) against the golden vectors captured from the reference and against the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+from tests.golden import replay_inputs as RI
+from oracle import backbone_ref as BR
+from oracle import sampler_ref as ora
+from bidiff.model.backbone import DiffusionBackbone
+from bidiff.model.diffusion import DiscreteMaskingDiffusion
+
+pytestmark = pytest.mark.gpu
+BLOB = np.load(os.path.join(H.GOLDEN, "model.npz"))
+BF16_TOL = 2e-2   # relative error bound stated for bf16 logits
+
+
+def tiny_model(name):
+    cfg = RI.BACKBONE_CFGS[name]
+    torch.manual_seed(7)
+    bb = DiffusionBackbone(**cfg).eval()
+    RI.perturb_state_dict(bb.state_dict(), 11)
+    return cfg, bb
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+@pytest.mark.parametrize("name", list(RI.BACKBONE_CFGS))
+def test_backbone_logits_match_reference_golden(gpu_device, name):
+    cfg, bb = tiny_model(name)
+    bb = bb.to(gpu_device)
+    L = 24 if name != "tiny_h4" else 150
+    ids, attn, t = RI.backbone_inputs(cfg, 21, B=5, L=L)
+    ti, ta, tt = (torch.from_numpy(x).to(gpu_device) for x in (ids, attn, t))
+    with torch.no_grad():
+        got = bb(ti, tt, ta).float().cpu().numpy()
+        got_nm = bb(ti, tt, None).float().cpu().numpy()
+        got_2d = bb(ti, tt.unsqueeze(-1), ta).float().cpu().numpy()
+    assert got.shape == (5, L, cfg["vocab_size"]) and np.isfinite(got).all()
+    assert rel_err(got, BLOB[f"{name}/logits_masked"]) < BF16_TOL
+    assert rel_err(got_nm, BLOB[f"{name}/logits_nomask"]) < BF16_TOL
+    assert rel_err(got_2d, BLOB[f"{name}/logits_t2d"]) < BF16_TOL
+    with torch.no_grad():
+        pooled = bb.get_pooled_output(ti[:3], tt[:3], ta[:3], "mean").cpu().numpy()
+        pmax = bb.get_pooled_output(ti[:3], tt[:3], ta[:3], "max").cpu().numpy()
+        pcls = bb.get_pooled_output(ti[:3], tt[:3], ta[:3], "cls").cpu().numpy()
+    assert rel_err(pooled, BLOB[f"{name}/pooled_mean"]) < BF16_TOL
+    assert rel_err(pmax, BLOB[f"{name}/pooled_max"]) < BF16_TOL
+    assert rel_err(pcls, BLOB[f"{name}/pooled_cls"]) < BF16_TOL
+
+
+def test_small_config_logits_match_oracle(gpu_device):
+    """The benchmark architecture (d384 / 6 layers / 3 heads of 128) and the 6-head variant."""
+    for heads in (3, 6):
+        cfg = dict(RI.SMALL_CFG, num_heads=heads, dropout=0.0)
+        torch.manual_seed(42)
+        bb = DiffusionBackbone(**cfg).eval()
+        RI.perturb_state_dict(bb.state_dict(), 5)
+        sd = {k: v.clone() for k, v in bb.state_dict().items()}
+        ids, attn, t = RI.backbone_inputs(cfg, 3, B=6, L=128)
+        with torch.no_grad():
+            ref = BR.logits(sd, cfg, torch.from_numpy(ids), torch.from_numpy(t), torch.from_numpy(attn)).numpy()
+            bbg = bb.to(gpu_device)
+            got = bbg(torch.from_numpy(ids).to(gpu_device), torch.from_numpy(t).to(gpu_device),
+                      torch.from_numpy(attn).to(gpu_device)).cpu().numpy()
+        assert rel_err(got, ref) < BF16_TOL
+
+
+def test_cpu_tensors_fail_loudly():
+    cfg, bb = tiny_model("tiny_h2")
+    ids, attn, t = RI.backbone_inputs(cfg, 21)
+    with pytest.raises(RuntimeError):
+        bb(torch.from_numpy(ids), torch.from_numpy(t), torch.from_numpy(attn))
+
+
+@pytest.mark.parametrize("tag,bos,eos,use_attn", [("a", 2, 3, True), ("b", 2, 3, False), ("c", None, None, True)])
+def test_forward_process_bit_exact_vs_reference(gpu_device, tag, bos, eos, use_attn):
+    ids, attn, t = BLOB["fp/ids"], BLOB["fp/attn"], BLOB["fp/t"]
+    m = DiscreteMaskingDiffusion(torch.nn.Identity(), num_steps=50, mask_token_id=1, pad_token_id=0,
+                                 bos_token_id=bos, eos_token_id=eos).to(gpu_device)
+    noisy, ind = m.forward_process(torch.from_numpy(ids).to(gpu_device), torch.from_numpy(t).to(gpu_device),
+                                   torch.from_numpy(attn).to(gpu_device) if use_attn else None,
+                                   uniforms=torch.from_numpy(BLOB[f"fp/{tag}_u"]).to(gpu_device))
+    assert noisy.dtype == torch.long and ind.dtype == torch.bool
+    np.testing.assert_array_equal(noisy.cpu().numpy(), BLOB[f"fp/{tag}_noisy"])
+    np.testing.assert_array_equal(ind.cpu().numpy(), BLOB[f"fp/{tag}_ind"])
+
+
+def test_forward_process_philox_matches_oracle_at_scale(gpu_device):
+    """Counter-based stream: bit-exact against the oracle on a ragged batch, plus the size-
+    independent properties at a large batch (never touches PAD/BOS/EOS, rate follows the schedule)."""
+    rs = np.random.RandomState(0)
+    B, L, T = 64, 128, 50
+    ids = rs.randint(5, 803, size=(B, L)).astype(np.int64)
+    lens = rs.randint(2, L + 1, size=B)
+    attn = (np.arange(L)[None] < lens[:, None]).astype(np.int64)
+    ids[attn == 0] = 0
+    ids[:, 0] = 2
+    ids[np.arange(B), lens - 1] = 3
+    t = rs.randint(1, T + 1, size=B).astype(np.int64)
+    m = DiscreteMaskingDiffusion(torch.nn.Identity(), num_steps=T, mask_token_id=1, pad_token_id=0,
+                                 bos_token_id=2, eos_token_id=3).to(gpu_device)
+    m.corruption_rng = "philox"
+    torch.manual_seed(5)
+    seed = int(torch.randint(0, 2**62, (1,)).item())
+    torch.manual_seed(5)
+    noisy, ind = m.forward_process(torch.from_numpy(ids).to(gpu_device), torch.from_numpy(t).to(gpu_device),
+                                   torch.from_numpy(attn).to(gpu_device))
+    o_noisy, o_ind = ora.corrupt(ids, attn, t, m.mask_schedule.cpu().numpy(), None, 1, 0, 2, 3, seed=seed)
+    np.testing.assert_array_equal(noisy.cpu().numpy(), o_noisy)
+    np.testing.assert_array_equal(ind.cpu().numpy(), o_ind)
+    # large batch properties
+    B2 = 4096
+    ids2 = torch.randint(5, 803, (B2, L), device=gpu_device)
+    ids2[:, 0] = 2
+    ids2[:, -1] = 3
+    t2 = torch.full((B2,), 25, device=gpu_device)
+    n2, i2 = m.forward_process(ids2, t2, torch.ones_like(ids2))
+    assert not i2[:, 0].any() and not i2[:, -1].any()
+    assert torch.equal(n2[~i2], ids2[~i2]) and (n2[i2] == 1).all()
+    rate = i2[:, 1:-1].float().mean().item()
+    assert abs(rate - float(m.mask_schedule[25])) < 5e-3
