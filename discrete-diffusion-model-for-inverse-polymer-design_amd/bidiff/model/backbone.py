@@ -235,6 +235,7 @@ class DiffusionBackbone(nn.Module):
         With autograd recording and parameters that require grad this runs the training
         path (activations saved for the HIP backward kernels); otherwise the inference path.
         """
+        _lib.require_device(input_ids, "DiffusionBackbone.forward")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from ..training.autograd import backbone_forward_train
             return backbone_forward_train(self, input_ids, timesteps, attention_mask)

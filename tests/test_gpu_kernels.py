@@ -110,7 +110,8 @@ def test_attention_key_padding(gpu_device, dh, Hh, L):
         mask[b, :n] = 1
     mask[4, 2] = 0  # a hole in the middle
     out = torch.full((B * L, d), float("nan"), dtype=torch.bfloat16, device=dev)
-    rc = _lib.lib().bd_attention_fwd(_lib.ptr(qkv.to(dev)), _lib.ptr(mask.to(dev)), _lib.ptr(out), None, B, L, Hh,
+    d_qkv, d_mask = qkv.to(dev), mask.to(dev)   # keep the device copies alive across the launch
+    rc = _lib.lib().bd_attention_fwd(_lib.ptr(d_qkv), _lib.ptr(d_mask), _lib.ptr(out), None, B, L, Hh,
                                      dh, _s())
     _lib.check(rc, "attention")
     torch.cuda.synchronize()
@@ -120,7 +121,7 @@ def test_attention_key_padding(gpu_device, dh, Hh, L):
     assert got.view(B, L, d)[3].abs().max().item() == 0.0, "fully padded sequence must give exact zeros"
     assert (got - ref).abs().max().item() < 2e-2
     # no mask at all
-    rc = _lib.lib().bd_attention_fwd(_lib.ptr(qkv.to(dev)), None, _lib.ptr(out), None, B, L, Hh, dh, _s())
+    rc = _lib.lib().bd_attention_fwd(_lib.ptr(d_qkv), None, _lib.ptr(out), None, B, L, Hh, dh, _s())
     _lib.check(rc, "attention")
     torch.cuda.synchronize()
     assert (out.float().cpu() - ref_attention(qkv, None, B, L, Hh, dh)).abs().max().item() < 2e-2
@@ -136,7 +137,8 @@ def test_layernorm(gpu_device, M, d):
     ob = torch.empty(M, d, dtype=torch.bfloat16, device=dev)
     of = torch.empty(M, d, device=dev)
     st = torch.empty(M, 2, device=dev)
-    rc = _lib.lib().bd_layernorm(_lib.ptr(x.to(dev)), _lib.ptr(gm.to(dev)), _lib.ptr(bt.to(dev)), _lib.ptr(ob),
+    dx, dg, db = x.to(dev), gm.to(dev), bt.to(dev)
+    rc = _lib.lib().bd_layernorm(_lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), _lib.ptr(ob),
                                  _lib.ptr(of), _lib.ptr(st), M, d, 1e-5, _s())
     _lib.check(rc, "layernorm")
     torch.cuda.synchronize()
@@ -154,8 +156,9 @@ def test_embed(gpu_device):
     ids = torch.randint(0, V, (B, L), generator=g)
     t = torch.randint(0, T, (B,), generator=g)
     x = torch.empty(B * L, d, device=dev)
-    rc = _lib.lib().bd_embed(_lib.ptr(ids.to(dev)), _lib.ptr(t.to(dev)), _lib.ptr(tok.to(dev)), _lib.ptr(pos.to(dev)),
-                             _lib.ptr(tim.to(dev)), _lib.ptr(x), B, L, d, _s())
+    dv = [a.to(dev) for a in (ids, t, tok, pos, tim)]
+    rc = _lib.lib().bd_embed(_lib.ptr(dv[0]), _lib.ptr(dv[1]), _lib.ptr(dv[2]), _lib.ptr(dv[3]),
+                             _lib.ptr(dv[4]), _lib.ptr(x), B, L, d, _s())
     _lib.check(rc, "embed")
     torch.cuda.synchronize()
     ref = tok[ids] + pos[:L][None] + tim[t][:, None]

@@ -70,7 +70,7 @@ def test_sampler_end_to_end_replayed_by_oracle(gpu_device, variant, kw):
     assert ids.dtype == torch.long and ids.is_cuda and len(strings) == B
     assert (out != tok.mask_token_id).all()
     cid = tb.count_id
-    if variant != "group":
+    if variant != "group" and not kw.get("lengths") and not natural:   # very short rows cannot hold two
         assert ((out == cid).sum(1) == 2).all(), "exactly two stars / placeholders after the repairs"
 
 
