@@ -11,6 +11,19 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libbidiff_hip.so")
 
 _lib = None
+_weights_generation = 0
+
+
+def weights_generation():
+    return _weights_generation
+
+
+def bump_weights_generation():
+    """Called after parameters were updated in place by a kernel (torch's version counters do
+    not see that): invalidates every cached bf16 weight copy."""
+    global _weights_generation
+    _weights_generation += 1
+
 
 c_i64p = C.c_void_p
 VP = C.c_void_p
@@ -78,6 +91,17 @@ SIGNATURES = {
     "bd_embed": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP]),
     "bd_layernorm": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_float, VP]),
     "bd_gemm_bf16": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
+    "bd_gemm_bf16_aux": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
+    "bd_masked_ce_fwd": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, VP]),
+    "bd_masked_ce_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, VP]),
+    "bd_layernorm_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, VP]),
+    "bd_gemm_wgrad_bf16": (C.c_int, [VP, C.c_int, VP, C.c_int, VP, C.c_int, C.c_int, C.c_int, VP]),
+    "bd_colsum_bf16": (C.c_int, [VP, C.c_int, VP, C.c_int, C.c_int, VP]),
+    "bd_attention_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
+    "bd_embed_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
+    "bd_sumsq_f32": (C.c_int, [VP, C.c_longlong, VP, VP]),
+    "bd_adamw_step": (C.c_int, [VP, VP, VP, VP, C.c_longlong] + [C.c_float] * 7 + [VP, C.c_float, VP]),
+    "bd_cast_f32_to_bf16": (C.c_int, [VP, VP, C.c_longlong, VP]),
     "bd_attention_fwd": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "bd_mask_to_bytes": (C.c_int, [VP, VP, C.c_longlong, VP]),
     "bd_backbone_workspace_bytes": (C.c_longlong, [C.POINTER(BackboneDesc), C.c_int, C.c_int]),

@@ -123,7 +123,7 @@ class DiffusionBackbone(nn.Module):
 
     # ------------------------------------------------------------------ packing
     def _pack_key(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (_lib.weights_generation(),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def packed(self) -> _Packed:
         """bf16 weight copies and the bd_backbone_desc; rebuilt when any parameter changed."""

@@ -1,0 +1,271 @@
+"""Autograd bridge of the training step: forward passes that save what the HIP backward
+kernels need, and backward passes that chain those kernels.
+
+``backbone_forward_train`` is what ``DiffusionBackbone.forward`` runs when autograd is
+recording (reference call site: ``DiscreteMaskingDiffusion.forward``, diffusion.py:156, under
+``BackboneTrainer._train_step``, trainer_backbone.py:434-439); ``masked_cross_entropy`` is
+``_compute_loss`` (diffusion.py:169-209). Dropout is not applied (the kernels implement the
+``dropout = 0`` network).
+"""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+
+
+def _s():
+    return _lib.stream_handle()
+
+
+def _ck(rc, what):
+    if rc != 0:
+        _lib.check(rc, what)
+
+
+def _gemm(A, W, bias, out, M, n_pad, n_real, K, ldc, epi, aux_in=None, aux_out=None):
+    _ck(_lib.lib().bd_gemm_bf16_aux(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(aux_in),
+                                    _lib.ptr(aux_out), M, n_pad, n_real, K, ldc, epi, _s()), "bd_gemm_bf16")
+
+
+def _ln(x, g, b, out_bf16, stats, M, d, eps):
+    _ck(_lib.lib().bd_layernorm(_lib.ptr(x), _lib.ptr(g), _lib.ptr(b), _lib.ptr(out_bf16), None, _lib.ptr(stats),
+                                M, d, eps, _s()), "bd_layernorm")
+
+
+def _ln_bwd(dy, x, stats, g, dres, dx, dg, db, M, d):
+    _ck(_lib.lib().bd_layernorm_bwd(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(stats), _lib.ptr(g), _lib.ptr(dres),
+                                    _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), M, d, _s()), "bd_layernorm_bwd")
+
+
+def _wgrad(dY, X, dW, M, N, K):
+    _ck(_lib.lib().bd_gemm_wgrad_bf16(_lib.ptr(dY), dY.shape[-1], _lib.ptr(X), X.shape[-1], _lib.ptr(dW), M, N, K,
+                                      _s()), "bd_gemm_wgrad_bf16")
+
+
+def _colsum(dY, out, M, N):
+    _ck(_lib.lib().bd_colsum_bf16(_lib.ptr(dY), dY.shape[-1], _lib.ptr(out), M, N, _s()), "bd_colsum_bf16")
+
+
+def _to_bf16(x, out):
+    _ck(_lib.lib().bd_cast_f32_to_bf16(_lib.ptr(x), _lib.ptr(out), x.numel(), _s()), "bd_cast_f32_to_bf16")
+
+
+class _TrainWeights:
+    """bf16 copies (and transposes for the data-gradient GEMMs) of the current parameters."""
+
+    def __init__(self, model):
+        d, V = model.hidden_size, model.vocab_size
+        bf = torch.bfloat16
+        self.layers = []
+        with torch.no_grad():
+            for blk in model.layers:
+                a = blk.attn
+                wqkv = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0)
+                self.layers.append({
+                    "wqkv": wqkv.to(bf).contiguous(), "wqkvT": wqkv.t().to(bf).contiguous(),
+                    "bqkv": torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0).float().contiguous(),
+                    "wo": a.out_proj.weight.to(bf).contiguous(), "woT": a.out_proj.weight.t().to(bf).contiguous(),
+                    "w1": blk.ffn.fc1.weight.to(bf).contiguous(), "w1T": blk.ffn.fc1.weight.t().to(bf).contiguous(),
+                    "w2": blk.ffn.fc2.weight.to(bf).contiguous(), "w2T": blk.ffn.fc2.weight.t().to(bf).contiguous(),
+                })
+            self.vpad = (V + 127) // 128 * 128
+            wout = torch.zeros(self.vpad, d, dtype=bf, device=model.output_proj.weight.device)
+            wout[:V] = model.output_proj.weight.to(bf)
+            self.wout = wout
+            self.woutT = wout.t().contiguous()
+
+
+def _train_weights(model):
+    key = model._pack_key()
+    tw = getattr(model, "_train_w", None)
+    if tw is None or tw[0] != key:
+        tw = (key, _TrainWeights(model))
+        model._train_w = tw
+    return tw[1]
+
+
+class _BackboneFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, ids, timesteps, keymask, *params):
+        lib = _lib.lib()
+        B, L = ids.shape
+        M = B * L
+        d, F, V, H = model.hidden_size, model.ffn_hidden_size, model.vocab_size, model.num_heads
+        dev = ids.device
+        bf = torch.bfloat16
+        eps = float(model.final_norm.eps)
+        tw = _train_weights(model)
+        x = torch.empty(M, d, device=dev)
+        _ck(lib.bd_embed(_lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(model.token_embedding.weight),
+                         _lib.ptr(model.position_embedding.weight), _lib.ptr(model.timestep_embedding.weight),
+                         _lib.ptr(x), B, L, d, _s()), "bd_embed")
+        saved = []
+        for blk, w in zip(model.layers, tw.layers):
+            s = {"x_in": x}
+            s["st1"] = torch.empty(M, 2, device=dev)
+            s["h1"] = torch.empty(M, d, dtype=bf, device=dev)
+            _ln(x, blk.norm1.weight, blk.norm1.bias, s["h1"], s["st1"], M, d, eps)
+            s["qkv"] = torch.empty(M, 3 * d, dtype=bf, device=dev)
+            _gemm(s["h1"], w["wqkv"], w["bqkv"], s["qkv"], M, 3 * d, 3 * d, d, 3 * d, 0)
+            s["att"] = torch.empty(M, d, dtype=bf, device=dev)
+            s["lse"] = torch.empty(B, H, L, device=dev)
+            _ck(lib.bd_attention_fwd(_lib.ptr(s["qkv"]), _lib.ptr(keymask), _lib.ptr(s["att"]), _lib.ptr(s["lse"]),
+                                     B, L, H, d // H, _s()), "bd_attention_fwd")
+            x_mid = torch.empty(M, d, device=dev)
+            _gemm(s["att"], w["wo"], blk.attn.out_proj.bias, x_mid, M, d, d, d, d, 2, aux_in=x)
+            s["x_mid"] = x_mid
+            s["st2"] = torch.empty(M, 2, device=dev)
+            s["h2"] = torch.empty(M, d, dtype=bf, device=dev)
+            _ln(x_mid, blk.norm2.weight, blk.norm2.bias, s["h2"], s["st2"], M, d, eps)
+            s["u"] = torch.empty(M, F, dtype=bf, device=dev)
+            s["a"] = torch.empty(M, F, dtype=bf, device=dev)
+            _gemm(s["h2"], w["w1"], blk.ffn.fc1.bias, s["a"], M, F, F, d, F, 1, aux_out=s["u"])
+            x_out = torch.empty(M, d, device=dev)
+            _gemm(s["a"], w["w2"], blk.ffn.fc2.bias, x_out, M, d, d, F, d, 2, aux_in=x_mid)
+            saved.append(s)
+            x = x_out
+        stf = torch.empty(M, 2, device=dev)
+        hf = torch.empty(M, d, dtype=bf, device=dev)
+        _ln(x, model.final_norm.weight, model.final_norm.bias, hf, stf, M, d, eps)
+        logits = torch.empty(B, L, V, device=dev)
+        _gemm(hf, tw.wout, None, logits, M, tw.vpad, V, d, V, 3)
+        ctx.model, ctx.saved, ctx.tw = model, saved, tw
+        ctx.x_last, ctx.stf, ctx.hf = x, stf, hf
+        ctx.ids, ctx.timesteps, ctx.keymask = ids, timesteps, keymask
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        lib = _lib.lib()
+        model, tw = ctx.model, ctx.tw
+        ids, timesteps, keymask = ctx.ids, ctx.timesteps, ctx.keymask
+        B, L = ids.shape
+        M = B * L
+        d, F, V, H = model.hidden_size, model.ffn_hidden_size, model.vocab_size, model.num_heads
+        dev = ids.device
+        bf = torch.bfloat16
+        grads = {}
+
+        def zeros(*shape):
+            return torch.zeros(*shape, device=dev)
+
+        # vocabulary head
+        dl = torch.zeros(M, tw.vpad, dtype=bf, device=dev)
+        dl[:, :V] = dlogits.reshape(M, V)
+        dwout = zeros(tw.vpad, d)
+        _wgrad(dl, ctx.hf, dwout, M, tw.vpad, d)
+        grads[model.output_proj.weight] = dwout[:V]
+        dh = torch.empty(M, d, dtype=bf, device=dev)
+        _gemm(dl, tw.woutT, None, dh, M, d, d, tw.vpad, d, 0)
+        dx = torch.empty(M, d, device=dev)
+        dg, db = zeros(d), zeros(d)
+        _ln_bwd(dh, ctx.x_last, ctx.stf, model.final_norm.weight, None, dx, dg, db, M, d)
+        grads[model.final_norm.weight], grads[model.final_norm.bias] = dg, db
+
+        dy = torch.empty(M, d, dtype=bf, device=dev)
+        du = torch.empty(M, F, dtype=bf, device=dev)
+        datt = torch.empty(M, d, dtype=bf, device=dev)
+        dqkv = torch.empty(M, 3 * d, dtype=bf, device=dev)
+        delta = torch.empty(B, H, L, device=dev)
+        for blk, w, s in zip(reversed(model.layers), reversed(tw.layers), reversed(ctx.saved)):
+            # x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
+            _to_bf16(dx, dy)
+            dw2, db2 = zeros(d, F), zeros(d)
+            _wgrad(dy, s["a"], dw2, M, d, F)
+            _colsum(dy, db2, M, d)
+            _gemm(dy, w["w2T"], None, du, M, F, F, d, F, 4, aux_in=s["u"])
+            dw1, db1 = zeros(F, d), zeros(F)
+            _wgrad(du, s["h2"], dw1, M, F, d)
+            _colsum(du, db1, M, F)
+            _gemm(du, w["w1T"], None, dh, M, d, d, F, d, 0)
+            dg2, dbt2 = zeros(d), zeros(d)
+            _ln_bwd(dh, s["x_mid"], s["st2"], blk.norm2.weight, dx, dx, dg2, dbt2, M, d)
+            # x_mid = x_in + out_proj(attention(qkv(LN1(x_in))))
+            _to_bf16(dx, dy)
+            dwo, dbo = zeros(d, d), zeros(d)
+            _wgrad(dy, s["att"], dwo, M, d, d)
+            _colsum(dy, dbo, M, d)
+            _gemm(dy, w["woT"], None, datt, M, d, d, d, d, 0)
+            _ck(lib.bd_attention_bwd(_lib.ptr(s["qkv"]), _lib.ptr(keymask), _lib.ptr(s["att"]), _lib.ptr(datt),
+                                     _lib.ptr(s["lse"]), _lib.ptr(delta), _lib.ptr(dqkv), B, L, H, d // H, _s()),
+                "bd_attention_bwd")
+            dwqkv, dbqkv = zeros(3 * d, d), zeros(3 * d)
+            _wgrad(dqkv, s["h1"], dwqkv, M, 3 * d, d)
+            _colsum(dqkv, dbqkv, M, 3 * d)
+            _gemm(dqkv, w["wqkvT"], None, dh, M, d, d, 3 * d, d, 0)
+            dg1, dbt1 = zeros(d), zeros(d)
+            _ln_bwd(dh, s["x_in"], s["st1"], blk.norm1.weight, dx, dx, dg1, dbt1, M, d)
+            a = blk.attn
+            grads[a.q_proj.weight], grads[a.k_proj.weight], grads[a.v_proj.weight] = dwqkv[:d], dwqkv[d:2 * d], dwqkv[2 * d:]
+            grads[a.q_proj.bias], grads[a.k_proj.bias], grads[a.v_proj.bias] = dbqkv[:d], dbqkv[d:2 * d], dbqkv[2 * d:]
+            grads[a.out_proj.weight], grads[a.out_proj.bias] = dwo, dbo
+            grads[blk.ffn.fc1.weight], grads[blk.ffn.fc1.bias] = dw1, db1
+            grads[blk.ffn.fc2.weight], grads[blk.ffn.fc2.bias] = dw2, db2
+            grads[blk.norm1.weight], grads[blk.norm1.bias] = dg1, dbt1
+            grads[blk.norm2.weight], grads[blk.norm2.bias] = dg2, dbt2
+        dtok = zeros(*model.token_embedding.weight.shape)
+        dpos = zeros(*model.position_embedding.weight.shape)
+        dtim = zeros(*model.timestep_embedding.weight.shape)
+        _ck(lib.bd_embed_bwd(_lib.ptr(dx), _lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(dtok), _lib.ptr(dpos),
+                             _lib.ptr(dtim), B, L, d, int(model.pad_token_id), _s()), "bd_embed_bwd")
+        grads[model.token_embedding.weight] = dtok
+        grads[model.position_embedding.weight] = dpos
+        grads[model.timestep_embedding.weight] = dtim
+        out = [None, None, None, None]
+        for p in model.parameters():
+            g = grads.get(p)
+            out.append(g if (g is not None and p.requires_grad) else None)
+        ctx.saved = None
+        return tuple(out)
+
+
+def backbone_forward_train(model, input_ids, timesteps, attention_mask):
+    _lib.require_device(input_ids, "DiffusionBackbone.forward")
+    if model.hidden_size % 128 or model.ffn_hidden_size % 128:
+        raise ValueError("bidiff training path needs hidden and ffn sizes that are multiples of 128")
+    timesteps = model._check_inputs(input_ids, timesteps)
+    ids = input_ids.to(torch.long).contiguous()
+    keymask = model._keymask_bytes(attention_mask, ids)
+    for p in model.parameters():
+        if p.dtype != torch.float32 or not p.is_contiguous():
+            raise RuntimeError("bidiff training path expects contiguous fp32 parameters")
+    return _BackboneFn.apply(model, ids, timesteps, keymask, *model.parameters())
+
+
+class _MaskedCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets, indicator, attention_mask):
+        V = logits.shape[-1]
+        lg = logits.contiguous().view(-1, V)
+        M = lg.shape[0]
+        dev = lg.device
+        tg = targets.to(torch.long).contiguous().view(-1)
+        ind = indicator.to(torch.uint8).contiguous().view(-1)
+        am = None if attention_mask is None else attention_mask.to(torch.long).contiguous().view(-1)
+        sums = torch.zeros(2, device=dev)
+        lse = torch.empty(M, device=dev)
+        _ck(_lib.lib().bd_masked_ce_fwd(_lib.ptr(lg), _lib.ptr(tg), _lib.ptr(ind), _lib.ptr(am), _lib.ptr(lse),
+                                        _lib.ptr(sums), M, V, _s()), "bd_masked_ce_fwd")
+        ctx.save_for_backward(lg, tg, ind, lse, sums)
+        ctx.am = am
+        ctx.shape = logits.shape
+        cnt = sums[1]
+        return torch.where(cnt > 0, sums[0] / cnt.clamp(min=1e-30), torch.zeros_like(cnt))
+
+    @staticmethod
+    def backward(ctx, gout):
+        lg, tg, ind, lse, sums = ctx.saved_tensors
+        M, V = lg.shape
+        g = gout.reshape(1).float().contiguous()
+        dl = torch.empty_like(lg)
+        _ck(_lib.lib().bd_masked_ce_bwd(_lib.ptr(lg), _lib.ptr(tg), _lib.ptr(ind), _lib.ptr(ctx.am), _lib.ptr(lse),
+                                        _lib.ptr(sums), _lib.ptr(g), _lib.ptr(dl), M, V, _s()), "bd_masked_ce_bwd")
+        return dl.view(ctx.shape), None, None, None
+
+
+def masked_cross_entropy(logits, targets, mask_indicator, attention_mask=None):
+    _lib.require_device(logits, "masked cross-entropy")
+    if logits.dtype != torch.float32:
+        logits = logits.float()
+    return _MaskedCE.apply(logits, targets, mask_indicator, attention_mask)

@@ -1,0 +1,223 @@
+"""BackboneTrainer: the reference's training loop around the native training step.
+
+Drop-in for ``src/training/trainer_backbone.py`` (``BackboneTrainer``, :61-715): same
+constructor, ``train()`` / ``load_checkpoint()``, history dict, checkpoint dict layout
+(``epoch, global_step, model_state_dict, optimizer_state_dict, scheduler_state_dict, val_loss,
+best_val_loss, config``) and CSV files. Differences that follow from the native step:
+  * the denoiser always computes in bf16 on the MFMA path (``use_amp`` is accepted, autocast
+    and GradScaler are not needed: bf16 gradients are not scaled);
+  * AdamW + global-norm clipping are one fused kernel pair over a flat parameter buffer;
+  * data parallelism = one process per GPU; the flat gradient buffer is all-reduced (mean) in
+    a single RCCL call on optimizer steps only (accumulation micro-steps skip it, which is what
+    ``no_sync`` does in the reference, trainer_backbone.py:427-431).
+"""
+import csv
+import math
+from pathlib import Path
+from typing import Dict, Optional
+
+import torch
+import torch.distributed as dist
+from torch.optim.lr_scheduler import CosineAnnealingLR, LinearLR, SequentialLR
+
+from .optimizer import FlatAdamW
+from ..parallel import allreduce_mean_
+
+
+def _f(v, name):
+    try:
+        return float(v)
+    except (TypeError, ValueError) as e:
+        raise ValueError(f"training_backbone.{name} must be a number, got {v!r}") from e
+
+
+class BackboneTrainer:
+    def __init__(self, model, train_dataloader, val_dataloader, config: Dict, device: str = "cuda",
+                 output_dir: str = "results", step_dir: str = None, distributed: bool = False, rank: int = 0,
+                 world_size: int = 1, local_rank: Optional[int] = None):
+        self.model = model.to(device)
+        self.train_dataloader = train_dataloader
+        self.val_dataloader = val_dataloader
+        self.config = config
+        self.device = device
+        self.distributed = bool(distributed) and dist.is_available() and dist.is_initialized()
+        self.rank, self.world_size, self.local_rank = rank, world_size, local_rank
+        self.is_main_process = (not self.distributed) or rank == 0
+        self.output_dir = Path(output_dir)
+        self.step_dir = Path(step_dir) if step_dir else self.output_dir
+        self.checkpoint_dir = self.output_dir / "checkpoints"
+        self.metrics_dir = self.step_dir / "metrics"
+        if self.is_main_process:
+            self.checkpoint_dir.mkdir(parents=True, exist_ok=True)
+            self.metrics_dir.mkdir(parents=True, exist_ok=True)
+
+        opt = config.get("optimization", {})
+        self.use_amp = bool(opt.get("use_amp", False))
+        self.grad_accum_steps = int(opt.get("gradient_accumulation_steps", 1))
+        tc = config["training_backbone"]
+        self.learning_rate = _f(tc["learning_rate"], "learning_rate")
+        self.weight_decay = _f(tc["weight_decay"], "weight_decay")
+        self.warmup_steps = int(_f(tc["warmup_steps"], "warmup_steps"))
+        self.max_steps = int(_f(tc["max_steps"], "max_steps"))
+        self.gradient_clip_norm = _f(tc["gradient_clip_norm"], "gradient_clip_norm")
+        self.eval_every = int(_f(tc["eval_every"], "eval_every"))
+        self.save_every = int(_f(tc["save_every"], "save_every"))
+        self.num_epochs = int(_f(tc.get("num_epochs", 50), "num_epochs"))
+        ck = config.get("checkpointing", {})
+        self.save_best_only = ck.get("save_best_only", True)
+        self.save_last = ck.get("save_last", False)
+        self.save_periodic = ck.get("save_periodic", False)
+        if bool(opt.get("use_muon", False)) or str(opt.get("optimizer", "adamw")).lower().startswith("muon"):
+            raise NotImplementedError("bidiff: the Muon optimizer branch is not built; use AdamW")
+
+        if self.distributed:   # same start on every rank, as DDP's construction broadcast does
+            for t in list(self.model.parameters()) + list(self.model.buffers()):
+                dist.broadcast(t.data, src=0)
+        self.optimizer = FlatAdamW(self.model.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay)
+        warm = LinearLR(self.optimizer, start_factor=0.01, end_factor=1.0, total_iters=max(1, self.warmup_steps))
+        cos = CosineAnnealingLR(self.optimizer, T_max=max(1, self.max_steps - self.warmup_steps), eta_min=1e-6)
+        self.scheduler = SequentialLR(self.optimizer, schedulers=[warm, cos], milestones=[self.warmup_steps])
+
+        self.global_step = 0
+        self.best_val_loss = float("inf")
+        self.train_losses, self.val_losses, self.val_steps, self.learning_rates = [], [], [], []
+        self.epoch_train_losses, self.epoch_val_losses = [], []
+
+    # ------------------------------------------------------------------ helpers
+    def _get_model_state(self):
+        return self.model.state_dict()
+
+    def _reduce_mean(self, value: float) -> float:
+        if not self.distributed:
+            return value
+        t = torch.tensor(value, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return (t / self.world_size).item()
+
+    def _barrier(self):
+        if self.distributed:
+            dist.barrier()
+
+    # ------------------------------------------------------------------ the hot step
+    def train_step_device(self, input_ids, attention_mask, should_step: bool = True):
+        """One micro-batch on device tensors; returns the (unscaled) loss as a device scalar
+        without synchronising the host (reference _train_step, trainer_backbone.py:414-457)."""
+        out = self.model(input_ids, attention_mask)
+        loss = out["loss"] / self.grad_accum_steps
+        loss.backward()
+        if should_step:
+            if self.distributed:
+                allreduce_mean_(self.optimizer.flat_grad, self.world_size)
+            self.optimizer.step(max_norm=self.gradient_clip_norm)
+            self.optimizer.zero_grad()
+            self.scheduler.step()
+        return out["loss"].detach()
+
+    def _train_step(self, batch, should_step: bool) -> float:
+        ids = batch["input_ids"].to(self.device)
+        am = batch["attention_mask"].to(self.device)
+        return float(self.train_step_device(ids, am, should_step).item())
+
+    def _validate(self) -> float:
+        self.model.eval()
+        total, n = 0.0, 0
+        with torch.no_grad():
+            for batch in self.val_dataloader:
+                out = self.model(batch["input_ids"].to(self.device), batch["attention_mask"].to(self.device))
+                total += out["loss"].item()
+                n += 1
+        return self._reduce_mean(total / max(n, 1))
+
+    def _train_epoch(self, epoch: int) -> float:
+        self.model.train()
+        total, n = 0.0, 0
+        if self.distributed:
+            for s in (getattr(self.train_dataloader, "sampler", None), getattr(self.train_dataloader, "batch_sampler", None)):
+                if hasattr(s, "set_epoch"):
+                    s.set_epoch(epoch)
+        nb = len(self.train_dataloader)
+        for i, batch in enumerate(self.train_dataloader):
+            if self.global_step >= self.max_steps:
+                break
+            should_step = ((i + 1) % self.grad_accum_steps == 0) or (i + 1 == nb)
+            loss = self._train_step(batch, should_step)
+            total += loss
+            n += 1
+            if self.is_main_process:
+                self.train_losses.append(loss)
+                self.learning_rates.append(self.optimizer.param_groups[0]["lr"])
+            if should_step:
+                self.global_step += 1
+                if self.global_step % self.eval_every == 0:
+                    val = self._validate()
+                    self.model.train()
+                    if self.is_main_process:
+                        self.val_losses.append(val)
+                        self.val_steps.append(self.global_step)
+                        self._save_checkpoint(val, epoch)
+                    self._barrier()
+                if (not self.save_best_only) and self.save_periodic and self.global_step % self.save_every == 0:
+                    if self.is_main_process:
+                        torch.save(self._checkpoint(float("nan"), epoch), self.checkpoint_dir / f"backbone_step_{self.global_step}.pt")
+                    self._barrier()
+        self._barrier()
+        return self._reduce_mean(total / max(n, 1))
+
+    def train(self) -> Dict:
+        val_loss, epoch = float("nan"), 0
+        for epoch in range(self.num_epochs):
+            tr = self._train_epoch(epoch)
+            val_loss = self._validate()
+            self.epoch_train_losses.append(tr)
+            self.epoch_val_losses.append(val_loss)
+            self._save_checkpoint(val_loss, epoch)
+            self._barrier()
+            if self.is_main_process:
+                print(f"Epoch {epoch + 1}/{self.num_epochs} - Train Loss: {tr:.4f} - Val Loss: {val_loss:.4f} - "
+                      f"LR: {self.optimizer.param_groups[0]['lr']:.2e}")
+            if self.global_step >= self.max_steps:
+                break
+        self._save_checkpoint(val_loss, epoch, final=True)
+        self._save_history()
+        return {"train_losses": self.train_losses, "val_losses": self.val_losses,
+                "learning_rates": self.learning_rates, "epoch_train_losses": self.epoch_train_losses,
+                "epoch_val_losses": self.epoch_val_losses, "best_val_loss": self.best_val_loss,
+                "fp8_phase2_eval": None}
+
+    # ------------------------------------------------------------------ checkpoints / history
+    def _checkpoint(self, val_loss, epoch):
+        return {"epoch": epoch, "global_step": self.global_step, "model_state_dict": self._get_model_state(),
+                "optimizer_state_dict": self.optimizer.state_dict(), "scheduler_state_dict": self.scheduler.state_dict(),
+                "val_loss": val_loss, "best_val_loss": self.best_val_loss, "config": self.config}
+
+    def _save_checkpoint(self, val_loss: float, epoch: int, final: bool = False):
+        if not self.is_main_process:
+            return
+        if not math.isnan(val_loss) and val_loss < self.best_val_loss:
+            self.best_val_loss = val_loss
+            torch.save(self._checkpoint(val_loss, epoch), self.checkpoint_dir / "backbone_best.pt")
+        if final and (self.save_last or not self.save_best_only):
+            torch.save(self._checkpoint(val_loss, epoch), self.checkpoint_dir / "backbone_last.pt")
+
+    def _save_history(self):
+        if not self.is_main_process:
+            return
+
+        def dump(name, header, rows):
+            with open(self.metrics_dir / name, "w", newline="") as f:
+                w = csv.writer(f)
+                w.writerow(header)
+                w.writerows(rows)
+        dump("backbone_loss_curve.csv", ["step", "train_loss", "learning_rate"],
+             [(i, l, lr) for i, (l, lr) in enumerate(zip(self.train_losses, self.learning_rates))])
+        dump("backbone_val_loss.csv", ["step", "val_loss"], list(zip(self.val_steps, self.val_losses)))
+        dump("backbone_epoch_loss_curve.csv", ["epoch", "train_loss", "val_loss"],
+             [(i + 1, a, b) for i, (a, b) in enumerate(zip(self.epoch_train_losses, self.epoch_val_losses))])
+
+    def load_checkpoint(self, checkpoint_path: str):
+        ck = torch.load(checkpoint_path, map_location=self.device, weights_only=False)  # file written by this class
+        self.model.load_state_dict(ck["model_state_dict"])
+        self.optimizer.load_state_dict(ck["optimizer_state_dict"])
+        self.scheduler.load_state_dict(ck["scheduler_state_dict"])
+        self.global_step = ck["global_step"]
+        self.best_val_loss = ck["best_val_loss"]

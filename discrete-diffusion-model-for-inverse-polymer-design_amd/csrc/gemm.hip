@@ -22,7 +22,7 @@ enum Epi : int {
   EPI_BIAS_GELU_BF16 = 1,  // out bf16 = gelu(acc + bias)   (erf form, F.gelu default)
   EPI_BIAS_RESID_F32 = 2,  // out fp32 += acc + bias        (residual stream, in place)
   EPI_F32 = 3,             // out fp32 = acc (+ bias if given), columns >= n_real dropped
-  EPI_BF16_NOBIAS_T = 4    // reserved
+  EPI_DGELU_BF16 = 4       // out bf16 = (acc + bias) * gelu'(aux)   (aux = pre-activation, bf16)
 };
 
 struct GemmArgs {
@@ -30,6 +30,8 @@ struct GemmArgs {
   const unsigned short* W;   // [Npad, K] bf16, Npad % 128 == 0 (zero rows past n_real)
   const float* bias;         // [n_real] or null
   void* out;                 // bf16 or fp32, row stride ldc elements
+  const void* aux_in;        // EPI 2: residual input fp32 (null = out itself); EPI 4: pre-activation bf16
+  void* aux_out;             // EPI 1: optional bf16 copy of the pre-activation (acc + bias)
   int M, Npad, K, n_real, ldc;
   int tiles_n, n_tiles;
 };
@@ -37,8 +39,25 @@ struct GemmArgs {
 __device__ __forceinline__ int swz_a(int row) { return row & 7; }
 __device__ __forceinline__ int swz_w(int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); }
 
+// erf by Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, far below bf16 resolution)
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  float p = 1.061405429f;
+  p = p * t + -1.453152027f;
+  p = p * t + 1.421413741f;
+  p = p * t + -0.284496736f;
+  p = p * t + 0.254829592f;
+  const float y = 1.0f - p * t * __expf(-ax * ax);
+  return copysignf(y, x);
+}
 __device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+  return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f));
+}
+// d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
+__device__ __forceinline__ float gelu_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752f));
+  return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 
 template <int EPI>
@@ -172,10 +191,31 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[4 * tn + r] = acc[tn][tm][r] + bv[4 * tn + r];
-    if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16) {
+    if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_DGELU_BF16) {
       if (EPI == EPI_BIAS_GELU_BF16) {
+        if (p.aux_out != nullptr) {
+          unsigned short* uo = (unsigned short*)p.aux_out + (size_t)m * p.ldc + nb;
+          u32x4 lo, hi;
+          lo[0] = bd_pack_bf16x2(v[0], v[1]);   lo[1] = bd_pack_bf16x2(v[2], v[3]);
+          lo[2] = bd_pack_bf16x2(v[4], v[5]);   lo[3] = bd_pack_bf16x2(v[6], v[7]);
+          hi[0] = bd_pack_bf16x2(v[8], v[9]);   hi[1] = bd_pack_bf16x2(v[10], v[11]);
+          hi[2] = bd_pack_bf16x2(v[12], v[13]); hi[3] = bd_pack_bf16x2(v[14], v[15]);
+          *(u32x4*)(uo) = lo;
+          *(u32x4*)(uo + 8) = hi;
+        }
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = gelu_erf(v[j]);
+      }
+      if (EPI == EPI_DGELU_BF16) {
+        const unsigned short* ui = (const unsigned short*)p.aux_in + (size_t)m * p.ldc + nb;
+        const u32x4 lo = *(const u32x4*)(ui), hi = *(const u32x4*)(ui + 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[2 * e] *= gelu_grad(__uint_as_float(lo[e] << 16));
+          v[2 * e + 1] *= gelu_grad(__uint_as_float(lo[e] & 0xffff0000u));
+          v[8 + 2 * e] *= gelu_grad(__uint_as_float(hi[e] << 16));
+          v[8 + 2 * e + 1] *= gelu_grad(__uint_as_float(hi[e] & 0xffff0000u));
+        }
       }
       unsigned short* o = (unsigned short*)p.out + (size_t)m * p.ldc + nb;
       u32x4 lo, hi;
@@ -187,9 +227,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
       *(u32x4*)(o + 8) = hi;
     } else if (EPI == EPI_BIAS_RESID_F32) {
       float* o = (float*)p.out + (size_t)m * p.ldc + nb;
+      const float* ri = p.aux_in ? (const float*)p.aux_in + (size_t)m * p.ldc + nb : o;
 #pragma unroll
       for (int j4 = 0; j4 < 4; ++j4) {
-        f32x4 x = *(const f32x4*)(o + 4 * j4);
+        f32x4 x = *(const f32x4*)(ri + 4 * j4);
         x[0] += v[4 * j4 + 0]; x[1] += v[4 * j4 + 1]; x[2] += v[4 * j4 + 2]; x[3] += v[4 * j4 + 3];
         *(f32x4*)(o + 4 * j4) = x;
       }
@@ -212,11 +253,13 @@ int launch(const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
-// epilogue: 0 bias->bf16, 1 bias+gelu->bf16, 2 fp32 out += acc+bias, 3 fp32 out (ragged n)
-extern "C" int bd_gemm_bf16(const void* A, const void* W, const float* bias, void* out,
-                            int M, int n_pad, int n_real, int K, int ldc, int epilogue,
-                            void* stream) {
+// epilogue: 0 bias->bf16, 1 bias+gelu->bf16, 2 fp32 out = resid + acc+bias, 3 fp32 out (ragged n),
+//           4 bf16 out = (acc+bias) * gelu'(aux_in)
+extern "C" int bd_gemm_bf16_aux(const void* A, const void* W, const float* bias, void* out,
+                                const void* aux_in, void* aux_out, int M, int n_pad, int n_real, int K,
+                                int ldc, int epilogue, void* stream) {
   BD_REQUIRE(A && W && out, "bd_gemm_bf16: null operand");
+  BD_REQUIRE(epilogue >= 0 && epilogue <= 4, "bd_gemm_bf16: unknown epilogue %d", epilogue);
   BD_REQUIRE(M > 0 && K > 0 && n_pad > 0, "bd_gemm_bf16: empty shape M=%d N=%d K=%d", M, n_pad, K);
   BD_REQUIRE(n_pad % BN == 0, "bd_gemm_bf16: weight rows %d must be padded to a multiple of %d", n_pad, BN);
   BD_REQUIRE(K % BK == 0, "bd_gemm_bf16: K=%d must be a multiple of %d", K, BK);
@@ -226,6 +269,8 @@ extern "C" int bd_gemm_bf16(const void* A, const void* W, const float* bias, voi
   BD_REQUIRE(ldc >= n_real, "bd_gemm_bf16: ldc=%d < n=%d", ldc, n_real);
   GemmArgs a;
   a.A = (const unsigned short*)A; a.W = (const unsigned short*)W; a.bias = bias; a.out = out;
+  a.aux_in = aux_in; a.aux_out = aux_out;
+  BD_REQUIRE(epilogue != EPI_DGELU_BF16 || aux_in != nullptr, "bd_gemm_bf16: epilogue 4 needs the pre-activation");
   a.M = M; a.Npad = n_pad; a.K = K; a.n_real = n_real; a.ldc = ldc;
   a.tiles_n = n_pad / BN;
   const long long tiles_m = ((long long)M + BM - 1) / BM;
@@ -238,6 +283,12 @@ extern "C" int bd_gemm_bf16(const void* A, const void* W, const float* bias, voi
     case EPI_BIAS_GELU_BF16: return launch<EPI_BIAS_GELU_BF16>(a, s);
     case EPI_BIAS_RESID_F32: return launch<EPI_BIAS_RESID_F32>(a, s);
     case EPI_F32: return launch<EPI_F32>(a, s);
+    case EPI_DGELU_BF16: return launch<EPI_DGELU_BF16>(a, s);
     default: return bd_fail(BD_ERR_ARG, "bd_gemm_bf16: unknown epilogue %d", epilogue);
   }
+}
+
+extern "C" int bd_gemm_bf16(const void* A, const void* W, const float* bias, void* out, int M, int n_pad,
+                            int n_real, int K, int ldc, int epilogue, void* stream) {
+  return bd_gemm_bf16_aux(A, W, bias, out, nullptr, nullptr, M, n_pad, n_real, K, ldc, epilogue, stream);
 }

@@ -1,2 +1,744 @@
-// training-step kernels (backward passes, loss, optimizer) live here
+// Training-step kernels (gfx950): masked cross-entropy forward/backward, LayerNorm backward,
+// weight-gradient GEMM, bias column sums, attention backward, embedding backward, global
+// gradient norm and the fused AdamW update.
 #include "bd_common.h"
+#include "bidiff.h"
+
+namespace {
+
+// =====================================================================================
+// Masked cross-entropy. Only rows with a non-zero weight (masked by the corruption AND not
+// padding) are read; sums[0] += sum(ce * w), sums[1] += sum(w).
+// =====================================================================================
+__device__ __forceinline__ float row_weight(const unsigned char* ind, const long long* attn, long long m) {
+  if (!ind[m]) return 0.f;
+  return attn ? (float)attn[m] : 1.f;
+}
+
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits,
+                                                     const long long* __restrict__ targets,
+                                                     const unsigned char* __restrict__ ind,
+                                                     const long long* __restrict__ attn,
+                                                     float* __restrict__ lse_out, float* __restrict__ sums,
+                                                     int M, int V) {
+  __shared__ float part[8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  float lsum = 0.f, wsum = 0.f;
+  if (row < M) {
+    const float w = row_weight(ind, attn, row);
+    float lse = 0.f;
+    if (w != 0.f) {
+      const float* x = logits + (size_t)row * V;
+      float mx = -INFINITY;
+      for (int v = lane; v < V; v += 64) mx = fmaxf(mx, x[v]);
+      mx = bd_wave_max(mx);
+      float se = 0.f;
+      for (int v = lane; v < V; v += 64) se += __expf(x[v] - mx);
+      se = bd_wave_sum(se);
+      lse = mx + __logf(se);
+      const float ce = lse - x[targets[row]];
+      lsum = ce * w;
+      wsum = w;
+    }
+    if (lane == 0) lse_out[row] = lse;
+  }
+  if (lane == 0) { part[wave] = lsum; part[4 + wave] = wsum; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float a = (part[0] + part[1]) + (part[2] + part[3]);
+    const float b = (part[4] + part[5]) + (part[6] + part[7]);
+    if (b != 0.f) { atomicAdd(&sums[0], a); atomicAdd(&sums[1], b); }
+  }
+}
+
+// dlogits = g * w / count * (softmax - onehot); zero rows where w == 0 or count == 0
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits,
+                                                     const long long* __restrict__ targets,
+                                                     const unsigned char* __restrict__ ind,
+                                                     const long long* __restrict__ attn,
+                                                     const float* __restrict__ lse, const float* __restrict__ sums,
+                                                     const float* __restrict__ gout, float* __restrict__ dlogits,
+                                                     int M, int V) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float cnt = sums[1];
+  const float w = row_weight(ind, attn, row);
+  float* d = dlogits + (size_t)row * V;
+  if (w == 0.f || cnt == 0.f) {
+    for (int v = lane; v < V; v += 64) d[v] = 0.f;
+    return;
+  }
+  const float coef = gout[0] * w / cnt;
+  const float* x = logits + (size_t)row * V;
+  const float l = lse[row];
+  const int tgt = (int)targets[row];
+  for (int v = lane; v < V; v += 64) d[v] = coef * (__expf(x[v] - l) - (v == tgt ? 1.f : 0.f));
+}
+
+// =====================================================================================
+// LayerNorm backward: dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma;
+// dgamma += sum dy * xhat, dbeta += sum dy. One wave per row, 8 rows per wave.
+// =====================================================================================
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short* __restrict__ dy,
+                                                            const float* __restrict__ x,
+                                                            const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma,
+                                                            const float* dres, float* dx,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int M, int d) {
+  constexpr int RPW = 8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = d / 4;
+  f32x4 gm[NV], ag[NV], ab[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int i = lane + 64 * j;
+    gm[j] = i < nv ? ((const f32x4*)gamma)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    ag[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    ab[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const int row0 = (blockIdx.x * 4 + wave) * RPW;
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int row = row0 + rr;
+    if (row >= M) break;
+    const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
+    f32x4 xh[NV], g[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int i = lane + 64 * j;
+      if (i < nv) {
+        const f32x4 xv = ((const f32x4*)(x + (size_t)row * d))[i];
+        const u32x2 dw = *(const u32x2*)(dy + (size_t)row * d + 4 * i);
+        f32x4 dv;
+        dv[0] = __uint_as_float(dw[0] << 16); dv[1] = __uint_as_float(dw[0] & 0xffff0000u);
+        dv[2] = __uint_as_float(dw[1] << 16); dv[3] = __uint_as_float(dw[1] & 0xffff0000u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[j][e] = (xv[e] - mean) * rstd;
+          g[j][e] = dv[e] * gm[j][e];
+          s1 += g[j][e];
+          s2 += g[j][e] * xh[j][e];
+          ag[j][e] += dv[e] * xh[j][e];
+          ab[j][e] += dv[e];
+        }
+      } else {
+        xh[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        g[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    s1 = bd_wave_sum(s1) / (float)d;
+    s2 = bd_wave_sum(s2) / (float)d;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int i = lane + 64 * j;
+      if (i < nv) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rstd * (g[j][e] - s1 - xh[j][e] * s2);
+        if (dres != nullptr) {
+          const f32x4 r = ((const f32x4*)(dres + (size_t)row * d))[i];
+          o[0] += r[0]; o[1] += r[1]; o[2] += r[2]; o[3] += r[3];
+        }
+        ((f32x4*)(dx + (size_t)row * d))[i] = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int i = lane + 64 * j;
+    if (i < nv) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        atomicAdd(dgamma + 4 * i + e, ag[j][e]);
+        atomicAdd(dbeta + 4 * i + e, ab[j][e]);
+      }
+    }
+  }
+}
+
+// =====================================================================================
+// Weight-gradient GEMM: dW[N,K] += dY[M,N]^T * X[M,K]  (bf16 in, fp32 atomic accumulate).
+// Both operands are token-major in memory while the MFMA wants the token index contiguous
+// per lane: tiles are staged row-major into LDS and read with the transposing LDS read.
+// 128 x 128 output tile per workgroup, 64 tokens per step, the token range split over
+// gridDim.y workgroups.
+// =====================================================================================
+__device__ __forceinline__ int tile_off(int row, int ch) {   // 256-byte rows, swizzled 16-byte chunks
+  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+__device__ __forceinline__ s16x4 lds_read_tr(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const unsigned short* __restrict__ dY, int ldy,
+                                                       const unsigned short* __restrict__ X, int ldx,
+                                                       float* __restrict__ dW, int M, int N, int K,
+                                                       int tiles_k, int tokens_per_split) {
+  constexpr int TB = 64 * 256;   // bytes of one 64-token x 128-column tile
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TB];
+  unsigned char* const Ys = smem;
+  unsigned char* const Xs = smem + 2 * TB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int g = lane >> 4, c = lane & 15;
+  const int n0 = (blockIdx.x / tiles_k) * 128, k0 = (blockIdx.x % tiles_k) * 128;
+  const int m_begin = blockIdx.y * tokens_per_split;
+  int m_end = m_begin + tokens_per_split;
+  m_end = m_end < M ? m_end : M;
+  if (m_begin >= m_end) return;
+  const int steps = (m_end - m_begin + 63) / 64;
+
+  // staging: thread -> rows (tid/16 + 16 i), chunk tid%16
+  const int srow = tid >> 4, sch = tid & 15;
+  u32x4 ry[4], rx[4];
+  auto gload = [&](int st) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m_begin + st * 64 + srow + 16 * i;
+      if (m < m_end) {
+        ry[i] = *(const u32x4*)(dY + (size_t)m * ldy + n0 + sch * 8);
+        rx[i] = *(const u32x4*)(X + (size_t)m * ldx + k0 + sch * 8);
+      } else {
+        ry[i] = (u32x4){0u, 0u, 0u, 0u};
+        rx[i] = (u32x4){0u, 0u, 0u, 0u};
+      }
+    }
+  };
+  auto swrite = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int off = tile_off(srow + 16 * i, sch);
+      *(u32x4*)(Ys + buf * TB + off) = ry[i];
+      *(u32x4*)(Xs + buf * TB + off) = rx[i];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  gload(0);
+  swrite(0);
+  __syncthreads();
+  const int q4 = c >> 2, p4 = c & 3;
+  for (int st = 0; st < steps; ++st) {
+    const int buf = st & 1;
+    const bool more = st + 1 < steps;
+    if (more) gload(st + 1);
+    const unsigned char* Yb = Ys + buf * TB;
+    const unsigned char* Xb = Xs + buf * TB;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int r0 = 32 * kk + 8 * g + q4;
+      bf16x8 fy[4], fx[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int chy = 8 * wn + 2 * t + (p4 >> 1), chx = 8 * wk + 2 * t + (p4 >> 1);
+        union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+        u.s.a = lds_read_tr(Yb + tile_off(r0, chy) + 8 * (p4 & 1));
+        u.s.b = lds_read_tr(Yb + tile_off(r0 + 4, chy) + 8 * (p4 & 1));
+        fy[t] = u.v;
+        u.s.a = lds_read_tr(Xb + tile_off(r0, chx) + 8 * (p4 & 1));
+        u.s.b = lds_read_tr(Xb + tile_off(r0 + 4, chx) + 8 * (p4 & 1));
+        fx[t] = u.v;
+      }
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int tk = 0; tk < 4; ++tk)
+          acc[tn][tk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[tn], fx[tk], acc[tn][tk], 0, 0, 0);
+    }
+    if (more) swrite(buf ^ 1);
+    __syncthreads();
+  }
+  // lane (g, c): n = n0 + 64 wn + 16 tn + 4 g + r, k = k0 + 64 wk + 16 tk + c
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + 64 * wn + 16 * tn + 4 * g + r;
+      float* o = dW + (size_t)n * K + k0 + 64 * wk + c;
+#pragma unroll
+      for (int tk = 0; tk < 4; ++tk) atomicAdd(o + 16 * tk, acc[tn][tk][r]);
+    }
+}
+
+// out[n] += sum_m dY[m, n]   (bias gradients)
+__global__ __launch_bounds__(256) void colsum_kernel(const unsigned short* __restrict__ dY, int ld,
+                                                     float* __restrict__ out, int M, int N, int rows_per_block) {
+  const int m0 = blockIdx.x * rows_per_block;
+  int m1 = m0 + rows_per_block;
+  m1 = m1 < M ? m1 : M;
+  for (int c8 = threadIdx.x; c8 < N / 8; c8 += 256) {
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int m = m0; m < m1; ++m) {
+      const u32x4 w = *(const u32x4*)(dY + (size_t)m * ld + c8 * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s[2 * e] += __uint_as_float(w[e] << 16);
+        s[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(out + c8 * 8 + e, s[e]);
+  }
+}
+
+// =====================================================================================
+// Attention backward, two kernels that each recompute the probabilities from the saved
+// log-sum-exp (no atomics, deterministic):
+//   dq kernel : a wave owns 16 queries, sweeps key tiles -> dQ, and delta = rowsum(dO * O)
+//   dkv kernel: a wave owns 16 keys, sweeps query tiles  -> dK, dV
+// Operand orientation mirrors the forward kernel (everything transposed so that the
+// owned index sits on the lane).
+// =====================================================================================
+constexpr int AT = 128;     // rows per staged tile
+constexpr int AROW = 256;   // LDS row stride in bytes
+
+template <int DH>
+__device__ __forceinline__ void stage_rows(unsigned char* dst, const unsigned short* src, size_t row_stride,
+                                           int first, int limit, int tid) {
+  constexpr int CPR = DH / 8;
+  for (int idx = tid; idx < AT * CPR; idx += 256) {
+    const int row = idx / CPR, ch = idx % CPR;
+    u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+    if (first + row < limit) v = *(const u32x4*)(src + (size_t)(first + row) * row_stride + ch * 8);
+    *(u32x4*)(dst + tile_off(row, ch)) = v;
+  }
+}
+
+template <int DH>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned short* __restrict__ qkv,
+                                                             const unsigned char* __restrict__ keymask,
+                                                             const unsigned short* __restrict__ O,
+                                                             const unsigned short* __restrict__ dO,
+                                                             const float* __restrict__ lse,
+                                                             float* __restrict__ delta,
+                                                             unsigned short* __restrict__ dqkv, int L, int H,
+                                                             float scale) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * AT * AROW + AT];
+  unsigned char* const Ks = smem;
+  unsigned char* const Vs = smem + AT * AROW;
+  unsigned char* const Ms = smem + 2 * AT * AROW;
+  constexpr int KS = DH / 32, DT = DH / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int d = H * DH;
+  const size_t row3 = (size_t)3 * d;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  int qr = q0 + c;
+  const bool qok = qr < L;
+  qr = qok ? qr : L - 1;
+  const size_t tok = (size_t)b * L + qr;
+
+  bf16x8 qf[KS], dof[KS];
+  float dl = 0.f;
+  {
+    const unsigned short* qp = qkv + tok * row3 + (size_t)h * DH + 8 * g;
+    const unsigned short* op = O + tok * d + (size_t)h * DH + 8 * g;
+    const unsigned short* dp = dO + tok * d + (size_t)h * DH + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      qf[ks] = *(const bf16x8*)(qp + 32 * ks);
+      dof[ks] = *(const bf16x8*)(dp + 32 * ks);
+      const bf16x8 ov = *(const bf16x8*)(op + 32 * ks);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dl += (float)dof[ks][e] * (float)ov[e];
+    }
+  }
+  dl += __shfl_xor(dl, 16, 64);
+  dl += __shfl_xor(dl, 32, 64);
+  const float lq = lse[((size_t)b * H + h) * L + qr];
+  if (qok && g == 0) delta[((size_t)b * H + h) * L + qr] = dl;
+
+  f32x4 acc[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int q4 = c >> 2, p4 = c & 3;
+
+  for (int kt0 = 0; kt0 < L; kt0 += AT) {
+    if (kt0 > 0) __syncthreads();
+    stage_rows<DH>(Ks, qkv + (size_t)b * L * row3 + d + (size_t)h * DH, row3, kt0, L, tid);
+    stage_rows<DH>(Vs, qkv + (size_t)b * L * row3 + 2 * d + (size_t)h * DH, row3, kt0, L, tid);
+    if (tid < AT) {
+      const int key = kt0 + tid;
+      Ms[tid] = key < L ? (keymask ? (keymask[(size_t)b * L + key] != 0) : 1) : 0;
+    }
+    __syncthreads();
+    bf16x8 dsf[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      bf16x8 frag;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int krow = 32 * s4 + 8 * (c >> 2) + 4 * half + (c & 3);
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8 ka = *(const bf16x8*)(Ks + tile_off(krow, 4 * ks + g));
+          const bf16x8 va = *(const bf16x8*)(Vs + tile_off(krow, 4 * ks + g));
+          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, dof[ks], dp, 0, 0, 0);
+        }
+        const int kb = 32 * s4 + 8 * g + 4 * half;
+        const unsigned int m4 = *(const unsigned int*)(Ms + kb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool vis = ((m4 >> (8 * r)) & 0xffu) != 0u && lq > -INFINITY;
+          const float p = vis ? __expf(s[r] * scale - lq) : 0.f;
+          frag[4 * half + r] = (__bf16)(p * (dp[r] - dl) * scale);
+        }
+      }
+      dsf[s4] = frag;
+    }
+    // dQ^T += K^T dS^T
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int r0 = 32 * s4 + 8 * g + q4, ch = 2 * dt + (p4 >> 1);
+        union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+        u.s.a = lds_read_tr(Ks + tile_off(r0, ch) + 8 * (p4 & 1));
+        u.s.b = lds_read_tr(Ks + tile_off(r0 + 4, ch) + 8 * (p4 & 1));
+        acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, dsf[s4], acc[dt], 0, 0, 0);
+      }
+  }
+  if (qok) {
+    unsigned short* op = dqkv + tok * row3 + (size_t)h * DH + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      u32x2 w;
+      w[0] = bd_pack_bf16x2(acc[dt][0], acc[dt][1]);
+      w[1] = bd_pack_bf16x2(acc[dt][2], acc[dt][3]);
+      *(u32x2*)(op + 16 * dt) = w;
+    }
+  }
+}
+
+template <int DH>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const unsigned short* __restrict__ qkv,
+                                                              const unsigned char* __restrict__ keymask,
+                                                              const unsigned short* __restrict__ dO,
+                                                              const float* __restrict__ lse,
+                                                              const float* __restrict__ delta,
+                                                              unsigned short* __restrict__ dqkv, int L, int H,
+                                                              float scale) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * AT * AROW + 2 * AT * 4];
+  unsigned char* const Qs = smem;
+  unsigned char* const Ds = smem + AT * AROW;
+  float* const Ls = (float*)(smem + 2 * AT * AROW);
+  float* const Dl = Ls + AT;
+  constexpr int KS = DH / 32, DT = DH / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int d = H * DH;
+  const size_t row3 = (size_t)3 * d;
+  const int k0 = blockIdx.x * 64 + wave * 16;
+  int kr = k0 + c;
+  const bool kok = kr < L;
+  kr = kok ? kr : L - 1;
+  const size_t tok = (size_t)b * L + kr;
+  const bool vis = kok && (keymask ? keymask[tok] != 0 : true);
+
+  bf16x8 kf[KS], vf[KS];
+  {
+    const unsigned short* kp = qkv + tok * row3 + d + (size_t)h * DH + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      kf[ks] = *(const bf16x8*)(kp + 32 * ks);
+      vf[ks] = *(const bf16x8*)(kp + d + 32 * ks);
+    }
+  }
+  f32x4 ak[DT], av[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) { ak[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; av[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  const int q4 = c >> 2, p4 = c & 3;
+
+  for (int qt0 = 0; qt0 < L; qt0 += AT) {
+    if (qt0 > 0) __syncthreads();
+    stage_rows<DH>(Qs, qkv + (size_t)b * L * row3 + (size_t)h * DH, row3, qt0, L, tid);
+    stage_rows<DH>(Ds, dO + (size_t)b * L * d + (size_t)h * DH, (size_t)d, qt0, L, tid);
+    if (tid < AT) {
+      const int q = qt0 + tid;
+      Ls[tid] = q < L ? lse[((size_t)b * H + h) * L + q] : INFINITY;
+      Dl[tid] = q < L ? delta[((size_t)b * H + h) * L + q] : 0.f;
+    }
+    __syncthreads();
+    bf16x8 pf[4], dsf[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      bf16x8 fp, fd;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int qrow = 32 * s4 + 8 * (c >> 2) + 4 * half + (c & 3);
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8 qa = *(const bf16x8*)(Qs + tile_off(qrow, 4 * ks + g));
+          const bf16x8 da = *(const bf16x8*)(Ds + tile_off(qrow, 4 * ks + g));
+          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[ks], dp, 0, 0, 0);
+        }
+        const int qb = 32 * s4 + 8 * g + 4 * half;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float lq = Ls[qb + r];
+          const bool on = vis && lq > -INFINITY && lq < INFINITY;
+          const float p = on ? __expf(s[r] * scale - lq) : 0.f;
+          fp[4 * half + r] = (__bf16)p;
+          fd[4 * half + r] = (__bf16)(p * (dp[r] - Dl[qb + r]) * scale);
+        }
+      }
+      pf[s4] = fp;
+      dsf[s4] = fd;
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int r0 = 32 * s4 + 8 * g + q4, ch = 2 * dt + (p4 >> 1);
+        union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+        u.s.a = lds_read_tr(Ds + tile_off(r0, ch) + 8 * (p4 & 1));
+        u.s.b = lds_read_tr(Ds + tile_off(r0 + 4, ch) + 8 * (p4 & 1));
+        av[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pf[s4], av[dt], 0, 0, 0);
+        u.s.a = lds_read_tr(Qs + tile_off(r0, ch) + 8 * (p4 & 1));
+        u.s.b = lds_read_tr(Qs + tile_off(r0 + 4, ch) + 8 * (p4 & 1));
+        ak[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, dsf[s4], ak[dt], 0, 0, 0);
+      }
+  }
+  if (kok) {
+    unsigned short* op = dqkv + tok * row3 + d + (size_t)h * DH + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      u32x2 w;
+      w[0] = bd_pack_bf16x2(ak[dt][0], ak[dt][1]);
+      w[1] = bd_pack_bf16x2(ak[dt][2], ak[dt][3]);
+      *(u32x2*)(op + 16 * dt) = w;
+      w[0] = bd_pack_bf16x2(av[dt][0], av[dt][1]);
+      w[1] = bd_pack_bf16x2(av[dt][2], av[dt][3]);
+      *(u32x2*)(op + d + 16 * dt) = w;
+    }
+  }
+}
+
+// =====================================================================================
+// Embedding backward: scatter-add the residual-stream gradient into the three tables.
+// =====================================================================================
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dx,
+                                                        const long long* __restrict__ ids,
+                                                        const long long* __restrict__ tsteps,
+                                                        float* __restrict__ dtok, float* __restrict__ dpos,
+                                                        float* __restrict__ dtim, int M, int L, int d, int pad_id) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const long long id = ids[row];
+  const long long t = tsteps[row / L];
+  const float* g = dx + (size_t)row * d;
+  float* a = dtok + (size_t)id * d;
+  float* p = dpos + (size_t)(row % L) * d;
+  float* c = dtim + (size_t)t * d;
+  const bool tok_ok = id != pad_id;
+  for (int i = lane; i < d; i += 64) {
+    const float v = g[i];
+    if (tok_ok) atomicAdd(a + i, v);
+    atomicAdd(p + i, v);
+    atomicAdd(c + i, v);
+  }
+}
+
+// =====================================================================================
+// Global gradient norm and fused AdamW over flat fp32 buffers.
+// =====================================================================================
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
+  __shared__ float part[4];
+  float s = 0.f;
+  const long long stride = (long long)gridDim.x * 256 * 4;
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n) {
+      const f32x4 v = *(const f32x4*)(x + i);
+      s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    } else {
+      for (long long j = i; j < n; ++j) s += x[j] * x[j];
+    }
+  }
+  s = bd_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, long long n,
+                                                    float lr, float beta1, float beta2, float eps, float wd,
+                                                    float bc1, float bc2_sqrt, const float* __restrict__ gsumsq,
+                                                    float max_norm) {
+  float coef = 1.f;
+  if (gsumsq != nullptr && max_norm > 0.f) {
+    const float norm = sqrtf(gsumsq[0]);
+    coef = fminf(1.f, max_norm / (norm + 1e-6f));
+  }
+  const float step_size = lr / bc1;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float gi = g[i] * coef;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = m[i] + (gi - m[i]) * (1.f - beta1);
+    const float vi = v[i] * beta2 + gi * gi * (1.f - beta2);
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= step_size * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+
+// x bf16 <- fp32 (flat), used to refresh the bf16 weight copies after an optimizer step
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y,
+                                                        long long n) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] = bd_f32_to_bf16(x[i]);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------- C ABI
+extern "C" int bd_masked_ce_fwd(const float* logits, const long long* targets, const unsigned char* indicator,
+                                const long long* attention_mask, float* lse, float* sums, int M, int V,
+                                void* stream) {
+  BD_REQUIRE(logits && targets && indicator && lse && sums, "bd_masked_ce_fwd: null operand");
+  BD_REQUIRE(M >= 0 && V > 0, "bd_masked_ce_fwd: bad shape");
+  if (M == 0) return BD_OK;
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, targets,
+                     indicator, attention_mask, lse, sums, M, V);
+  return bd_check_launch("bd_masked_ce_fwd");
+}
+
+extern "C" int bd_masked_ce_bwd(const float* logits, const long long* targets, const unsigned char* indicator,
+                                const long long* attention_mask, const float* lse, const float* sums,
+                                const float* grad_out, float* dlogits, int M, int V, void* stream) {
+  BD_REQUIRE(logits && targets && indicator && lse && sums && grad_out && dlogits, "bd_masked_ce_bwd: null operand");
+  BD_REQUIRE(M >= 0 && V > 0, "bd_masked_ce_bwd: bad shape");
+  if (M == 0) return BD_OK;
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, targets,
+                     indicator, attention_mask, lse, sums, grad_out, dlogits, M, V);
+  return bd_check_launch("bd_masked_ce_bwd");
+}
+
+extern "C" int bd_layernorm_bwd(const void* dy_bf16, const float* x, const float* stats, const float* gamma,
+                                const float* dres, float* dx, float* dgamma, float* dbeta, int M, int d,
+                                void* stream) {
+  BD_REQUIRE(dy_bf16 && x && stats && gamma && dx && dgamma && dbeta, "bd_layernorm_bwd: null operand");
+  BD_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 4096, "bd_layernorm_bwd: bad shape M=%d d=%d", M, d);
+  dim3 grid((M + 31) / 32), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned short* dy = (const unsigned short*)dy_bf16;
+  const int nv = (d / 4 + 63) / 64;
+  if (nv <= 1) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, block, 0, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d);
+  else if (nv <= 2) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, block, 0, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d);
+  else if (nv <= 4) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, 0, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d);
+  else if (nv <= 8) hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, block, 0, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d);
+  else hipLaunchKernelGGL(layernorm_bwd_kernel<16>, grid, block, 0, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d);
+  return bd_check_launch("bd_layernorm_bwd");
+}
+
+extern "C" int bd_gemm_wgrad_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, int M, int N, int K,
+                                  void* stream) {
+  BD_REQUIRE(dY && X && dW, "bd_gemm_wgrad_bf16: null operand");
+  BD_REQUIRE(M > 0 && N > 0 && K > 0 && N % 128 == 0 && K % 128 == 0,
+             "bd_gemm_wgrad_bf16: N=%d and K=%d must be multiples of 128", N, K);
+  BD_REQUIRE(ldy >= N && ldx >= K && ldy % 8 == 0 && ldx % 8 == 0, "bd_gemm_wgrad_bf16: bad leading dimension");
+  const int tiles_k = K / 128, tiles = (N / 128) * tiles_k;
+  int split = (1024 + tiles - 1) / tiles;
+  const int max_split = (M + 511) / 512;   // at least 8 token steps per workgroup
+  split = split > max_split ? max_split : split;
+  split = split < 1 ? 1 : split;
+  int per = ((M + split - 1) / split + 63) / 64 * 64;
+  split = (M + per - 1) / per;
+  hipLaunchKernelGGL(wgrad_kernel, dim3(tiles, split), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)dY, ldy, (const unsigned short*)X, ldx, dW, M, N, K, tiles_k, per);
+  return bd_check_launch("bd_gemm_wgrad_bf16");
+}
+
+extern "C" int bd_colsum_bf16(const void* dY, int ld, float* out, int M, int N, void* stream) {
+  BD_REQUIRE(dY && out && M > 0 && N > 0 && N % 8 == 0 && ld >= N && ld % 8 == 0, "bd_colsum_bf16: bad argument");
+  const int rows = 128;
+  hipLaunchKernelGGL(colsum_kernel, dim3((M + rows - 1) / rows), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)dY, ld, out, M, N, rows);
+  return bd_check_launch("bd_colsum_bf16");
+}
+
+extern "C" int bd_attention_bwd(const void* qkv, const unsigned char* keymask, const void* out, const void* dout,
+                                const float* lse, float* delta, void* dqkv, int B, int L, int H, int head_dim,
+                                void* stream) {
+  BD_REQUIRE(qkv && out && dout && lse && delta && dqkv, "bd_attention_bwd: null operand");
+  BD_REQUIRE(B > 0 && L > 0 && H > 0 && B <= 65535 && H <= 65535, "bd_attention_bwd: bad shape");
+  const float scale = 1.0f / sqrtf((float)head_dim);
+  dim3 grid((L + 63) / 64, H, B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned short* q = (const unsigned short*)qkv;
+  const unsigned short* o = (const unsigned short*)out;
+  const unsigned short* dO = (const unsigned short*)dout;
+  unsigned short* dq = (unsigned short*)dqkv;
+#define BD_LAUNCH_BWD(DH)                                                                                   \
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<DH>, grid, block, 0, s, q, keymask, o, dO, lse, delta, dq, L, H, scale); \
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<DH>, grid, block, 0, s, q, keymask, dO, lse, delta, dq, L, H, scale)
+  switch (head_dim) {
+    case 32: BD_LAUNCH_BWD(32); break;
+    case 64: BD_LAUNCH_BWD(64); break;
+    case 128: BD_LAUNCH_BWD(128); break;
+    default: return bd_fail(BD_ERR_UNSUPPORTED, "bd_attention_bwd: head_dim %d not in {32, 64, 128}", head_dim);
+  }
+#undef BD_LAUNCH_BWD
+  return bd_check_launch("bd_attention_bwd");
+}
+
+extern "C" int bd_embed_bwd(const float* dx, const long long* ids, const long long* timesteps, float* dtok,
+                            float* dpos, float* dtime, int B, int L, int d, int pad_id, void* stream) {
+  BD_REQUIRE(dx && ids && timesteps && dtok && dpos && dtime, "bd_embed_bwd: null operand");
+  BD_REQUIRE(B > 0 && L > 0 && d > 0, "bd_embed_bwd: bad shape");
+  const long long M = (long long)B * L;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dx, ids,
+                     timesteps, dtok, dpos, dtime, (int)M, L, d, pad_id);
+  return bd_check_launch("bd_embed_bwd");
+}
+
+extern "C" int bd_sumsq_f32(const float* x, long long n, float* out, void* stream) {
+  BD_REQUIRE(x && out && n >= 0, "bd_sumsq_f32: bad argument");
+  if (n == 0) return BD_OK;
+  long long blocks = (n + 4095) / 4096;
+  blocks = blocks > 2048 ? 2048 : blocks;
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, out);
+  return bd_check_launch("bd_sumsq_f32");
+}
+
+extern "C" int bd_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                             float lr, float beta1, float beta2, float eps, float weight_decay,
+                             float bias_correction1, float bias_correction2_sqrt, const float* grad_sumsq,
+                             float max_norm, void* stream) {
+  BD_REQUIRE(params && grads && exp_avg && exp_avg_sq && n >= 0, "bd_adamw_step: bad argument");
+  BD_REQUIRE(bias_correction1 > 0.f && bias_correction2_sqrt > 0.f, "bd_adamw_step: bias corrections must be > 0");
+  if (n == 0) return BD_OK;
+  long long blocks = (n + 255) / 256;
+  blocks = blocks > 4096 ? 4096 : blocks;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, grads,
+                     exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bias_correction1,
+                     bias_correction2_sqrt, grad_sumsq, max_norm);
+  return bd_check_launch("bd_adamw_step");
+}
+
+extern "C" int bd_cast_f32_to_bf16(const float* x, void* y, long long n, void* stream) {
+  BD_REQUIRE(x && y && n >= 0, "bd_cast_f32_to_bf16: bad argument");
+  if (n == 0) return BD_OK;
+  long long blocks = (n + 255) / 256;
+  blocks = blocks > 4096 ? 4096 : blocks;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
+                     (unsigned short*)y, n);
+  return bd_check_launch("bd_cast_f32_to_bf16");
+}

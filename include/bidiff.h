@@ -108,6 +108,15 @@ int bd_backbone_forward(const bd_backbone_desc* desc, const long long* ids,
                         void* workspace, long long workspace_bytes, void* hidden_out,
                         float* logits_out, void* stream);
 
+/* bd_gemm_bf16 with the extra operands some epilogues take:
+ *   epilogue 1: aux_out (optional) receives the bf16 pre-activation acc + bias (saved for backward)
+ *   epilogue 2: aux_in (optional) is the fp32 residual input; out = aux_in + acc + bias
+ *   epilogue 4: out bf16 = (acc + bias) * gelu'(aux_in), aux_in = bf16 pre-activation
+ * (no single reference line: the pieces autograd records for backbone.py:96-99,126-128). */
+int bd_gemm_bf16_aux(const void* A, const void* W, const float* bias, void* out, const void* aux_in,
+                     void* aux_out, int M, int n_pad, int n_real, int K, int ldc, int epilogue,
+                     void* stream);
+
 /* ---------------------------------------------------------------- q(x_t | x_0) */
 
 /* should_mask = (u < schedule[t[b]]) & (attention_mask == 1, or ids != pad when the mask is
@@ -120,6 +129,57 @@ int bd_corrupt(const long long* ids, const long long* attention_mask, const long
                long long* noisy_ids, unsigned char* mask_indicator, int B, int L, int mask_id,
                int pad_id, int bos_id, int eos_id, unsigned long long seed, long long seq_offset,
                void* stream);
+
+/* ---------------------------------------------------------------- training step */
+
+/* Masked cross-entropy (fp32): weight w[m] = indicator[m] * attention_mask[m] (1 without a mask);
+ * forward adds sum(ce * w) to sums[0] and sum(w) to sums[1] (caller zeroes sums) and stores the
+ * per-row log-sum-exp; backward writes dlogits = grad_out[0] * w / sums[1] * (softmax - onehot),
+ * all zeros when sums[1] == 0. Rows with w == 0 are never read.
+ * replaces DiscreteMaskingDiffusion._compute_loss, src/model/diffusion.py:169-209, and its autograd. */
+int bd_masked_ce_fwd(const float* logits, const long long* targets, const unsigned char* indicator,
+                     const long long* attention_mask, float* lse, float* sums, int M, int V, void* stream);
+int bd_masked_ce_bwd(const float* logits, const long long* targets, const unsigned char* indicator,
+                     const long long* attention_mask, const float* lse, const float* sums,
+                     const float* grad_out, float* dlogits, int M, int V, void* stream);
+
+/* LayerNorm backward from the saved (mean, rstd): dx = dres + dLN(dy) (dres may be null or alias dx),
+ * dgamma += ..., dbeta += ... (autograd of nn.LayerNorm, src/model/backbone.py:126,128,254). */
+int bd_layernorm_bwd(const void* dy_bf16, const float* x, const float* stats, const float* gamma,
+                     const float* dres, float* dx, float* dgamma, float* dbeta, int M, int d, void* stream);
+
+/* dW[N,K] += dY[M,N]^T * X[M,K] (bf16 in, fp32 accumulate with atomics); N, K multiples of 128.
+ * (autograd of nn.Linear weights, src/model/backbone.py:25-28,91-92,195). */
+int bd_gemm_wgrad_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, int M, int N, int K,
+                       void* stream);
+
+/* out[n] += sum_m dY[m,n] (bias gradients). */
+int bd_colsum_bf16(const void* dY, int ld, float* out, int M, int N, void* stream);
+
+/* Attention backward: dqkv [B*L, 3*H*head_dim] bf16 (dQ | dK | dV) from qkv, the forward output,
+ * its gradient and the saved log-sum-exp; delta [B,H,L] fp32 is scratch written by the call.
+ * (autograd of F.scaled_dot_product_attention, src/model/backbone.py:54-67). */
+int bd_attention_bwd(const void* qkv, const unsigned char* keymask, const void* out, const void* dout,
+                     const float* lse, float* delta, void* dqkv, int B, int L, int H, int head_dim,
+                     void* stream);
+
+/* Scatter-add of the embedding-sum gradient into the three tables (the pad row of the token table
+ * receives nothing, as nn.Embedding(padding_idx) does). (autograd of src/model/backbone.py:234-246). */
+int bd_embed_bwd(const float* dx, const long long* ids, const long long* timesteps, float* dtok, float* dpos,
+                 float* dtime, int B, int L, int d, int pad_id, void* stream);
+
+/* out[0] += sum x^2 (global gradient norm of clip_grad_norm_, src/training/trainer_backbone.py:446-449). */
+int bd_sumsq_f32(const float* x, long long n, float* out, void* stream);
+
+/* Fused AdamW over flat fp32 buffers with torch.optim.AdamW's update order; when grad_sumsq is
+ * given the gradients are first scaled by min(1, max_norm / (sqrt(grad_sumsq[0]) + 1e-6)).
+ * replaces optimizer.step() of shared/optimizer_setup.py:290-294 (AdamW branch). */
+int bd_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, float bias_correction1,
+                  float bias_correction2_sqrt, const float* grad_sumsq, float max_norm, void* stream);
+
+/* y (bf16) = x (fp32), flat. */
+int bd_cast_f32_to_bf16(const float* x, void* y, long long n, void* stream);
 
 /* ---------------------------------------------------------------- reverse step */
 

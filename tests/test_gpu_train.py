@@ -1,0 +1,313 @@
+"""GPU parity of the training-step kernels and of the whole training step (forward, backward,
+clip + AdamW) against fp32 PyTorch autograd of the CPU oracle and the reference golden vectors."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+from tests.golden import replay_inputs as RI
+from oracle import backbone_ref as BR
+from bidiff import _lib
+from bidiff.model.backbone import DiffusionBackbone
+from bidiff.model.diffusion import DiscreteMaskingDiffusion
+from bidiff.training import autograd as AG
+from bidiff.training.optimizer import FlatAdamW
+
+pytestmark = pytest.mark.gpu
+BLOB = np.load(os.path.join(H.GOLDEN, "model.npz"))
+
+
+def _s():
+    return _lib.stream_handle()
+
+
+def rel(a, b):
+    return float((a - b).norm() / b.norm().clamp(min=1e-12))
+
+
+def test_masked_ce_matches_reference_golden(gpu_device):
+    dev = gpu_device
+    lg = torch.from_numpy(BLOB["ce/logits"]).to(dev).requires_grad_(True)
+    tg, mi, am = (torch.from_numpy(BLOB[k]).to(dev) for k in ("ce/targets", "ce/ind", "ce/attn"))
+    loss = AG.masked_cross_entropy(lg, tg, mi, am)
+    loss.backward()
+    assert abs(loss.item() - float(BLOB["ce/loss"])) < 1e-5
+    assert np.abs(lg.grad.cpu().numpy() - BLOB["ce/dlogits"]).max() < 1e-6
+    lg2 = lg.detach().clone().requires_grad_(True)
+    zero = AG.masked_cross_entropy(lg2, tg, torch.zeros_like(mi), am)
+    zero.backward()
+    assert zero.item() == 0.0 and float(lg2.grad.abs().max()) == 0.0
+    assert abs(AG.masked_cross_entropy(lg.detach(), tg, mi, None).item() - float(BLOB["ce/loss_noattn"])) < 1e-5
+    # upstream gradient scaling (loss / grad_accum)
+    lg3 = lg.detach().clone().requires_grad_(True)
+    (AG.masked_cross_entropy(lg3, tg, mi, am) / 4).backward()
+    assert np.abs(lg3.grad.cpu().numpy() - BLOB["ce/dlogits"] / 4).max() < 1e-6
+
+
+@pytest.mark.parametrize("V", [39, 803])
+def test_masked_ce_large(gpu_device, V):
+    dev = gpu_device
+    g = torch.Generator().manual_seed(V)
+    M = 4000
+    lg = (torch.randn(M, V, generator=g) * 3).to(dev).requires_grad_(True)
+    tg = torch.randint(0, V, (M,), generator=g).to(dev)
+    mi = (torch.rand(M, generator=g) < 0.4).to(dev)
+    am = (torch.rand(M, generator=g) < 0.8).long().to(dev)
+    loss = AG.masked_cross_entropy(lg.view(40, 100, V), tg.view(40, 100), mi.view(40, 100), am.view(40, 100))
+    loss.backward()
+    ref_lg = lg.detach().clone().requires_grad_(True)
+    ref = BR.masked_ce(ref_lg.view(40, 100, V), tg.view(40, 100), mi.view(40, 100), am.view(40, 100))
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-5 * max(1, abs(ref.item()))
+    assert (lg.grad - ref_lg.grad).abs().max().item() < 1e-7 + 1e-4 * ref_lg.grad.abs().max().item()
+
+
+@pytest.mark.parametrize("M,d", [(50, 128), (1000, 384), (300, 1024)])
+def test_layernorm_backward(gpu_device, M, d):
+    dev = gpu_device
+    g = torch.Generator().manual_seed(M + d)
+    x = (torch.randn(M, d, generator=g) * 2 + 0.5).to(dev)
+    gm = (1 + 0.2 * torch.randn(d, generator=g)).to(dev)
+    bt = torch.randn(d, generator=g).to(dev)
+    dy = torch.randn(M, d, generator=g).to(dev).bfloat16()
+    dres = torch.randn(M, d, generator=g).to(dev)
+    st = torch.empty(M, 2, device=dev)
+    hb = torch.empty(M, d, dtype=torch.bfloat16, device=dev)
+    _lib.check(_lib.lib().bd_layernorm(_lib.ptr(x), _lib.ptr(gm), _lib.ptr(bt), _lib.ptr(hb), None, _lib.ptr(st), M, d, 1e-5, _s()), "ln")
+    dx = dres.clone()
+    dg, db = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+    _lib.check(_lib.lib().bd_layernorm_bwd(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(st), _lib.ptr(gm), _lib.ptr(dx), _lib.ptr(dx),
+                                           _lib.ptr(dg), _lib.ptr(db), M, d, _s()), "ln bwd")
+    torch.cuda.synchronize()
+    xr, gr, br = x.clone().requires_grad_(True), gm.clone().requires_grad_(True), bt.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr, (d,), gr, br, 1e-5).backward(dy.float())
+    assert rel(dx, xr.grad + dres) < 1e-5
+    assert rel(dg, gr.grad) < 1e-4 and rel(db, br.grad) < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 128, 128), (5000, 384, 1536), (3333, 1152, 384), (70, 896, 384)])
+def test_wgrad_and_colsum(gpu_device, M, N, K):
+    dev = gpu_device
+    g = torch.Generator().manual_seed(M + N + K)
+    dY = torch.randn(M, N, generator=g).to(dev).bfloat16()
+    X = torch.randn(M, K, generator=g).to(dev).bfloat16()
+    dW = torch.ones(N, K, device=dev)          # accumulates on top of existing content
+    bs = torch.ones(N, device=dev)
+    _lib.check(_lib.lib().bd_gemm_wgrad_bf16(_lib.ptr(dY), N, _lib.ptr(X), K, _lib.ptr(dW), M, N, K, _s()), "wgrad")
+    _lib.check(_lib.lib().bd_colsum_bf16(_lib.ptr(dY), N, _lib.ptr(bs), M, N, _s()), "colsum")
+    torch.cuda.synchronize()
+    ref = dY.float().t() @ X.float() + 1
+    assert rel(dW, ref) < 1e-5
+    assert rel(bs, dY.float().sum(0) + 1) < 1e-5
+
+
+def test_wgrad_exact_integers(gpu_device):
+    dev = gpu_device
+    M, N, K = 200, 256, 128
+    g = torch.Generator().manual_seed(0)
+    dY = torch.randint(-3, 4, (M, N), generator=g).float()
+    X = torch.randint(-3, 4, (M, K), generator=g).float()
+    dW = torch.zeros(N, K, device=dev)
+    a, b = dY.to(dev).bfloat16(), X.to(dev).bfloat16()
+    _lib.check(_lib.lib().bd_gemm_wgrad_bf16(_lib.ptr(a), N, _lib.ptr(b), K, _lib.ptr(dW), M, N, K, _s()), "wgrad")
+    torch.cuda.synchronize()
+    assert torch.equal(dW.cpu(), dY.t() @ X)
+
+
+def test_dgelu_epilogue_and_preactivation_save(gpu_device):
+    dev = gpu_device
+    M, N, K = 300, 256, 128
+    g = torch.Generator().manual_seed(2)
+    A = torch.randn(M, K, generator=g).to(dev).bfloat16()
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev).bfloat16()
+    bias = torch.randn(N, generator=g).to(dev)
+    u = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    a = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    AG._gemm(A, W, bias, a, M, N, N, K, N, 1, aux_out=u)
+    pre = A.float() @ W.float().t() + bias
+    assert rel(u.float(), pre) < 1e-2 and rel(a.float(), torch.nn.functional.gelu(pre)) < 1e-2
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    AG._gemm(A, W, None, out, M, N, N, K, N, 4, aux_in=u)
+    ur = u.float().requires_grad_(True)
+    torch.nn.functional.gelu(ur).sum().backward()
+    assert rel(out.float(), (A.float() @ W.float().t()) * ur.grad) < 1e-2
+
+
+@pytest.mark.parametrize("dh,Hh,L", [(32, 2, 24), (64, 2, 128), (128, 1, 128), (64, 3, 150), (128, 3, 300)])
+def test_attention_backward(gpu_device, dh, Hh, L):
+    dev = gpu_device
+    B = 4
+    d = Hh * dh
+    g = torch.Generator().manual_seed(dh + L)
+    qkv = torch.randn(B * L, 3 * d, generator=g).bfloat16()
+    dout = torch.randn(B * L, d, generator=g).bfloat16()
+    lengths = [L, max(2, L // 3), 0, L - 3]
+    mask = torch.zeros(B, L, dtype=torch.uint8)
+    for b, n in enumerate(lengths):
+        mask[b, :n] = 1
+    dq, dm, ddo = qkv.to(dev), mask.to(dev), dout.to(dev)
+    out = torch.empty(B * L, d, dtype=torch.bfloat16, device=dev)
+    lse = torch.empty(B, Hh, L, device=dev)
+    _lib.check(_lib.lib().bd_attention_fwd(_lib.ptr(dq), _lib.ptr(dm), _lib.ptr(out), _lib.ptr(lse), B, L, Hh, dh, _s()), "fwd")
+    dqkv = torch.full((B * L, 3 * d), float("nan"), dtype=torch.bfloat16, device=dev)
+    delta = torch.empty(B, Hh, L, device=dev)
+    _lib.check(_lib.lib().bd_attention_bwd(_lib.ptr(dq), _lib.ptr(dm), _lib.ptr(out), _lib.ptr(ddo), _lib.ptr(lse),
+                                           _lib.ptr(delta), _lib.ptr(dqkv), B, L, Hh, dh, _s()), "bwd")
+    torch.cuda.synchronize()
+    from tests.test_gpu_kernels import ref_attention
+    qr = qkv.float().requires_grad_(True)
+    ref_attention(qr, mask, B, L, Hh, dh).backward(dout.float())
+    got = dqkv.float().cpu()
+    assert torch.isfinite(got).all()
+    for name, sl in (("dQ", slice(0, d)), ("dK", slice(d, 2 * d)), ("dV", slice(2 * d, 3 * d))):
+        assert rel(got[:, sl], qr.grad[:, sl]) < 2e-2, name
+    assert got.view(B, L, 3 * d)[2].abs().max().item() == 0.0, "fully padded sequence: zero gradients"
+
+
+def test_embedding_backward(gpu_device):
+    dev = gpu_device
+    B, L, d, V, T = 8, 20, 128, 39, 21
+    g = torch.Generator().manual_seed(4)
+    ids = torch.randint(0, V, (B, L), generator=g)
+    t = torch.randint(0, T, (B,), generator=g)
+    dx = torch.randn(B * L, d, generator=g)
+    dtok, dpos, dtim = torch.zeros(V, d, device=dev), torch.zeros(64, d, device=dev), torch.zeros(T, d, device=dev)
+    a, b, c = ids.to(dev), t.to(dev), dx.to(dev)
+    _lib.check(_lib.lib().bd_embed_bwd(_lib.ptr(c), _lib.ptr(a), _lib.ptr(b), _lib.ptr(dtok), _lib.ptr(dpos), _lib.ptr(dtim),
+                                       B, L, d, 0, _s()), "embed bwd")
+    torch.cuda.synchronize()
+    tok = torch.nn.Embedding(V, d, padding_idx=0)
+    pos, tim = torch.nn.Embedding(64, d), torch.nn.Embedding(T, d)
+    (tok(ids) + pos(torch.arange(L))[None] + tim(t)[:, None]).backward(dx.view(B, L, d))
+    assert rel(dtok.cpu(), tok.weight.grad) < 1e-5 and dtok[0].abs().max().item() == 0.0
+    assert rel(dpos.cpu(), pos.weight.grad) < 1e-5 and rel(dtim.cpu(), tim.weight.grad) < 1e-5
+
+
+def test_fused_adamw_with_clip_matches_torch(gpu_device):
+    dev = gpu_device
+    g = torch.Generator().manual_seed(6)
+    shapes = [(37, 5), (128,), (64, 64), (3,)]
+    ps = [torch.nn.Parameter(torch.randn(*s, generator=g).to(dev)) for s in shapes]
+    rs = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ps]
+    opt = FlatAdamW(ps, lr=3e-3, weight_decay=0.05)
+    ref = torch.optim.AdamW(rs, lr=3e-3, weight_decay=0.05)
+    for step in range(5):
+        for p, r in zip(ps, rs):
+            gr = torch.randn(*r.shape, generator=g) * (10.0 if step % 2 == 0 else 0.01)
+            r.grad = gr.clone()
+            p.grad.copy_(gr.to(dev))
+        torch.nn.utils.clip_grad_norm_(rs, 1.0)
+        ref.step()
+        opt.step(max_norm=1.0)
+        opt.zero_grad()
+        for p, r in zip(ps, rs):
+            assert (p.detach().cpu() - r.detach()).abs().max().item() < 2e-6
+    sd = opt.state_dict()
+    assert set(sd["state"][0]) >= {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 5.0
+
+
+def _grad_setup(name, dev, B=6, L=24):
+    cfg = RI.BACKBONE_CFGS[name]
+    torch.manual_seed(7)
+    bb = DiffusionBackbone(**cfg)
+    RI.perturb_state_dict(bb.state_dict(), 11)
+    model = DiscreteMaskingDiffusion(bb, num_steps=cfg["num_diffusion_steps"], mask_token_id=1, pad_token_id=0,
+                                     bos_token_id=2, eos_token_id=3)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    ids, attn, t = RI.backbone_inputs(cfg, 33, B=B, L=L)
+    return cfg, model.to(dev), sd, torch.from_numpy(ids), torch.from_numpy(attn), torch.from_numpy(t)
+
+
+@pytest.mark.parametrize("name", ["tiny_h2", "tiny_h1"])
+def test_training_forward_backward_matches_oracle_autograd(gpu_device, name):
+    """loss and every parameter gradient of one training forward/backward vs fp32 autograd of the
+    CPU restatement (same corruption uniforms)."""
+    dev = gpu_device
+    cfg, model, sd, ids, attn, t = _grad_setup(name, dev)
+    model.train()
+    u = torch.rand(ids.shape, generator=torch.Generator().manual_seed(1))
+    noisy, ind = model.forward_process(ids.to(dev), t.to(dev), attn.to(dev), uniforms=u.to(dev))
+    logits = model.backbone(noisy, t.to(dev), attn.to(dev))
+    assert logits.requires_grad
+    loss = model._compute_loss(logits, ids.to(dev), ind, attn.to(dev))
+    loss.backward()
+    # oracle
+    ref_sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and k != "mask_schedule") for k, v in sd.items()}
+    rl = BR.logits(ref_sd, cfg, noisy.cpu(), t, attn, prefix="backbone.")
+    rloss = BR.masked_ce(rl, ids, ind.cpu(), attn)
+    rloss.backward()
+    assert abs(loss.item() - rloss.item()) < 2e-2 * abs(rloss.item())
+    worst = 0.0
+    for k, p in model.named_parameters():
+        gref = ref_sd[k].grad
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        if k.endswith("k_proj.bias"):
+            # shifting every key by the same vector does not change the softmax: the true gradient
+            # is zero (fp32 autograd returns rounding noise), so bound it absolutely instead
+            qb = ref_sd[k.replace("k_proj", "q_proj")].grad.norm().item()
+            assert p.grad.norm().item() < 0.1 * qb, k   # bf16 rounding of the summed dK rows
+            continue
+        e = rel(p.grad.cpu(), gref)
+        worst = max(worst, e)
+        assert e < 1e-1, (k, e)    # bf16 products: a few percent on the smallest gradients
+        cos = torch.nn.functional.cosine_similarity(p.grad.cpu().flatten(), gref.flatten(), dim=0).item()
+        assert cos > 0.995, (k, cos)
+    # position rows never used and the pad row get exactly zero
+    assert model.backbone.token_embedding.weight.grad[0].abs().max().item() == 0.0
+    assert model.backbone.position_embedding.weight.grad[ids.shape[1]:].abs().max().item() == 0.0
+
+
+def test_training_steps_follow_fp32_reference_trajectory(gpu_device):
+    """Five optimizer steps (corruption, forward, backward, clip 1.0, AdamW) on the GPU next to the
+    same five steps of the fp32 CPU restatement with torch.optim.AdamW: losses stay within bf16
+    tolerance and the parameters end up close."""
+    dev = gpu_device
+    cfg, model, sd, ids, attn, t = _grad_setup("tiny_h2", dev, B=16, L=24)
+    model.train()
+    opt = FlatAdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
+    ref_params = {k: torch.nn.Parameter(v.clone()) for k, v in sd.items() if k != "mask_schedule"}
+    ropt = torch.optim.AdamW(ref_params.values(), lr=1e-3, weight_decay=0.01)
+    g = torch.Generator().manual_seed(3)
+    losses, rlosses = [], []
+    for step in range(5):
+        tt = torch.randint(1, cfg["num_diffusion_steps"] + 1, (ids.shape[0],), generator=g)
+        u = torch.rand(ids.shape, generator=g)
+        noisy, ind = model.forward_process(ids.to(dev), tt.to(dev), attn.to(dev), uniforms=u.to(dev))
+        loss = model._compute_loss(model.backbone(noisy, tt.to(dev), attn.to(dev)), ids.to(dev), ind, attn.to(dev))
+        loss.backward()
+        opt.step(max_norm=1.0)
+        opt.zero_grad()
+        losses.append(loss.item())
+        rl = BR.masked_ce(BR.logits(ref_params, cfg, noisy.cpu(), tt, attn, prefix="backbone."), ids, ind.cpu(), attn)
+        ropt.zero_grad()
+        rl.backward()
+        torch.nn.utils.clip_grad_norm_(ref_params.values(), 1.0)
+        ropt.step()
+        rlosses.append(rl.item())
+    for a, b in zip(losses, rlosses):
+        assert abs(a - b) < 3e-2 * abs(b), (losses, rlosses)
+    for k, p in model.named_parameters():
+        assert (p.detach().cpu() - ref_params[k].detach()).abs().max().item() < 5e-3, k
+
+
+def test_trainer_runs_and_checkpoints(gpu_device, tmp_path):
+    from bidiff.training import BackboneTrainer
+    cfg, model, sd, ids, attn, t = _grad_setup("tiny_h2", gpu_device, B=8, L=24)
+    batches = [{"input_ids": ids, "attention_mask": attn} for _ in range(6)]
+    conf = {"optimization": {"use_amp": True, "gradient_accumulation_steps": 2},
+            "training_backbone": {"learning_rate": 1e-3, "weight_decay": 0.01, "warmup_steps": 2, "max_steps": 6,
+                                  "gradient_clip_norm": 1.0, "eval_every": 2, "save_every": 100, "num_epochs": 2},
+            "checkpointing": {"save_best_only": True}}
+    tr = BackboneTrainer(model, batches, batches[:2], conf, device=str(gpu_device), output_dir=str(tmp_path))
+    hist = tr.train()
+    assert len(hist["train_losses"]) == 12 and all(math.isfinite(x) for x in hist["train_losses"])
+    assert hist["train_losses"][-1] < hist["train_losses"][0]
+    ck = torch.load(tmp_path / "checkpoints" / "backbone_best.pt", map_location="cpu", weights_only=False)
+    assert set(ck) == {"epoch", "global_step", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict",
+                       "val_loss", "best_val_loss", "config"}
+    assert list(ck["model_state_dict"].keys()) == list(sd.keys())
+    assert (tmp_path / "metrics" / "backbone_loss_curve.csv").exists()
+    tr.load_checkpoint(str(tmp_path / "checkpoints" / "backbone_best.pt"))
