@@ -47,6 +47,71 @@ def cpu_baseline(sd, cfg, sampler, L, T, n_seq, threads):
                       f"{dt:.1f} s ({t_net:.1f} s denoiser, {t_step:.1f} s sampling loop)"}
 
 
+def train_bench(dev, rank, world, steps, warmup, batch=256, L=128):
+    """Second headline number: non-pad tokens/s of the SMILES_BPE training step (V = 803, T = 50,
+    per-rank batch 256, L = 128 padded, AdamW lr 3e-4 wd 0.01, clip 1.0; one gradient-bucket
+    all-reduce per step when world > 1)."""
+    import numpy as np
+    from bidiff.model.backbone import DiffusionBackbone
+    from bidiff.model.diffusion import DiscreteMaskingDiffusion
+    from bidiff.training.optimizer import FlatAdamW
+    from bidiff.parallel import allreduce_mean_
+    V, T = 803, 50
+    torch.manual_seed(42)
+    bb = DiffusionBackbone(V, 384, 6, 3, 1536, 256, T, 0.0, 0)
+    model = DiscreteMaskingDiffusion(bb, num_steps=T, mask_token_id=1, pad_token_id=0, bos_token_id=2,
+                                     eos_token_id=3).to(dev).train()
+    model.corruption_rng = "philox"
+    if world > 1:
+        for t_ in list(model.parameters()):
+            dist.broadcast(t_.data, src=0)
+    opt = FlatAdamW(model.parameters(), lr=3e-4, weight_decay=0.01)
+    rs = np.random.RandomState(1 + rank)
+    lens = np.clip(np.round(rs.normal(38.5, 15.0, size=batch)), 12, L).astype(np.int64)
+    ids = rs.randint(5, V, size=(batch, L)).astype(np.int64)
+    attn = (np.arange(L)[None] < lens[:, None]).astype(np.int64)
+    ids[attn == 0] = 0
+    ids[:, 0] = 2
+    ids[np.arange(batch), lens - 1] = 3
+    ids_d, attn_d = torch.from_numpy(ids).to(dev), torch.from_numpy(attn).to(dev)
+    tokens = int(attn.sum())
+
+    def step():
+        out = model(ids_d, attn_d)
+        out["loss"].backward()
+        if world > 1:
+            allreduce_mean_(opt.flat_grad, world)
+        opt.step(max_norm=1.0)
+        opt.zero_grad()
+        return out["loss"]
+
+    for _ in range(warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    tok = torch.tensor([float(tokens)], device=dev, dtype=torch.float64)
+    tm = torch.tensor([el], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tok, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    el = float(tm.item())
+    return {"metric": "train non-pad tokens/sec (Bi_Diffusion_SMILES_BPE training step)",
+            "value": float(tok.item()) * steps / el, "unit": "non-pad tokens/s",
+            "padded_tokens_per_s": world * batch * L * steps / el, "ms_per_step": 1e3 * el / steps,
+            "steps": steps, "warmup": warmup, "final_loss": float(loss.item()),
+            "config": {"workload": f"SMILES_BPE small backbone (V=803, T=50), per-GPU batch {batch}, L={L} padded, "
+                                   f"{tokens} non-pad tokens per rank-batch, dropout 0, AdamW + clip 1.0",
+                       "parallelism": f"dp{world}, one flat-gradient all-reduce per step"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,6 +122,7 @@ def main():
     ap.add_argument("--diffusion-steps", type=int, default=100)
     ap.add_argument("--cpu-seqs", type=int, default=24, help="sequences in the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-constraints", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=20, help="timed training steps (0 = skip the training leg)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,6 +184,11 @@ def main():
 
     # strings are decoded on the host outside the timed region (host tokenizer work)
     assert (ids != tok.mask_token_id).all()
+    train = None
+    if args.train_steps > 0:
+        del ids
+        torch.cuda.empty_cache()
+        train = train_bench(dev, rank, world, args.train_steps, 5)
 
     if rank == 0:
         total_seqs = world * B * args.steps
@@ -141,6 +212,8 @@ def main():
                          "flops_per_launch": fl.value / max(1, n_launch.value)},
             "whole_path_tflops": value / world * flops_seq / 1e12,
         }
+        if train is not None:
+            out["train"] = train
         if args.cpu_seqs > 0 and world == 1:
             threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
             out["cpu_baseline"] = cpu_baseline(sd_cpu, cfg, smp, L, T, args.cpu_seqs, threads)
