@@ -37,6 +37,9 @@ class LayerWeights(C.Structure):
         ("ln2_g", VP), ("ln2_b", VP),
         ("w_fc1", VP), ("b_fc1", VP),
         ("w_fc2", VP), ("b_fc2", VP),
+        ("w_qkv_ln", VP), ("b_qkv_ln", VP),
+        ("w_fc1_ln", VP), ("b_fc1_ln", VP),
+        ("ffn_pack", VP),
     ]
 
 
@@ -102,6 +105,12 @@ SIGNATURES = {
     "bd_sumsq_f32": (C.c_int, [VP, C.c_longlong, VP, VP]),
     "bd_adamw_step": (C.c_int, [VP, VP, VP, VP, C.c_longlong] + [C.c_float] * 7 + [VP, C.c_float, VP]),
     "bd_cast_f32_to_bf16": (C.c_int, [VP, VP, C.c_longlong, VP]),
+    "bd_gemm_panel_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "bd_gemm_panel": (C.c_int, [VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, VP]),
+    "bd_ffn_fused_supported": (C.c_int, [C.c_int, C.c_int]),
+    "bd_ffn_pack_bytes": (C.c_long, [C.c_int, C.c_int]),
+    "bd_ffn_pack_weights": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, VP]),
+    "bd_ffn_fused": (C.c_int, [VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_float, VP]),
     "bd_attention_fwd": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "bd_mask_to_bytes": (C.c_int, [VP, VP, C.c_longlong, VP]),
     "bd_backbone_workspace_bytes": (C.c_longlong, [C.POINTER(BackboneDesc), C.c_int, C.c_int]),

@@ -149,6 +149,7 @@ class DiffusionBackbone(nn.Module):
             return t
 
         layers = (_lib.LayerWeights * max(1, self.num_layers))()
+        L_ = _lib.lib()
         with torch.no_grad():
             for i, blk in enumerate(self.layers):
                 a = blk.attn
@@ -161,6 +162,22 @@ class DiffusionBackbone(nn.Module):
                 lw.ln2_g = f32(blk.norm2.weight).data_ptr(); lw.ln2_b = f32(blk.norm2.bias).data_ptr()
                 lw.w_fc1 = bf(blk.ffn.fc1.weight).data_ptr(); lw.b_fc1 = f32(blk.ffn.fc1.bias).data_ptr()
                 lw.w_fc2 = bf(blk.ffn.fc2.weight).data_ptr(); lw.b_fc2 = f32(blk.ffn.fc2.bias).data_ptr()
+                # LayerNorm folded into the following projection: LN(x) W^T + b =
+                # ((x - mean) * rstd) (W * gamma)^T + (b + W beta)   (fp32 fold, then one bf16 rounding)
+                wq32 = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0).float()
+                lw.w_qkv_ln = bf(wq32 * blk.norm1.weight.float()[None, :]).data_ptr()
+                lw.b_qkv_ln = f32(bqkv + wq32 @ blk.norm1.bias.float()).data_ptr()
+                w1 = blk.ffn.fc1.weight.float()
+                w1ln = bf(w1 * blk.norm2.weight.float()[None, :])
+                lw.w_fc1_ln = w1ln.data_ptr()
+                lw.b_fc1_ln = f32(blk.ffn.fc1.bias.float() + w1 @ blk.norm2.bias.float()).data_ptr()
+                # weight stream of the fused feed-forward kernel (fragment order, see ffn_fused.hip)
+                if L_.bd_ffn_fused_supported(d, F):
+                    pack = torch.empty(L_.bd_ffn_pack_bytes(d, F), dtype=torch.uint8, device=dev)
+                    keep.append(pack)
+                    _lib.check(L_.bd_ffn_pack_weights(w1ln.data_ptr(), lw.w_fc2, pack.data_ptr(), d, F,
+                                                      _lib.stream_handle()), "bd_ffn_pack_weights")
+                    lw.ffn_pack = pack.data_ptr()
             vpad = ((V + 127) // 128) * 128
             w_out = torch.zeros(vpad, d, dtype=torch.bfloat16, device=dev)
             w_out[:V] = self.output_proj.weight.detach().to(torch.bfloat16)

@@ -67,14 +67,33 @@ extern "C" int bd_backbone_forward(const bd_backbone_desc* desc, const long long
   const int d = c.d, F = c.ffn, Mi = (int)M;
 
   if ((rc = bd_embed(ids, timesteps, c.tok_emb, c.pos_emb, c.time_emb, x, B, L, d, stream))) return rc;
+  // Fused kernels whenever the shapes allow (LayerNorm folded into the QKV projection's row-panel
+  // kernel; the whole feed-forward block in one kernel); otherwise LayerNorm + tiled GEMMs. The
+  // residual projections (out_proj, unfused fc2) use the tiled GEMM, which is the faster one there.
+  const bool pan_qkv = bd_gemm_panel_supported(3 * d, d, 1) != 0;
+  const bool pan_fc1 = bd_gemm_panel_supported(F, d, 1) != 0;
+  const bool fused_ffn = bd_ffn_fused_supported(d, F) != 0;
   for (int i = 0; i < c.n_layers; ++i) {
     const bd_layer_weights& lw = c.layers[i];
-    if ((rc = bd_layernorm(x, lw.ln1_g, lw.ln1_b, h, nullptr, nullptr, Mi, d, c.ln_eps, stream))) return rc;
-    if ((rc = bd_gemm_bf16(h, lw.w_qkv, lw.b_qkv, qkv, Mi, 3 * d, 3 * d, d, 3 * d, 0, stream))) return rc;
+    if (pan_qkv && lw.w_qkv_ln && lw.b_qkv_ln) {
+      if ((rc = bd_gemm_panel(x, lw.w_qkv_ln, lw.b_qkv_ln, qkv, nullptr, Mi, 3 * d, d, 3 * d, 0, 1, c.ln_eps, stream))) return rc;
+    } else {
+      if ((rc = bd_layernorm(x, lw.ln1_g, lw.ln1_b, h, nullptr, nullptr, Mi, d, c.ln_eps, stream))) return rc;
+      if ((rc = bd_gemm_bf16(h, lw.w_qkv, lw.b_qkv, qkv, Mi, 3 * d, 3 * d, d, 3 * d, 0, stream))) return rc;
+    }
     if ((rc = bd_attention_fwd(qkv, keymask, att, nullptr, B, L, c.n_heads, d / c.n_heads, stream))) return rc;
     if ((rc = bd_gemm_bf16(att, lw.w_o, lw.b_o, x, Mi, d, d, d, d, 2, stream))) return rc;
-    if ((rc = bd_layernorm(x, lw.ln2_g, lw.ln2_b, h, nullptr, nullptr, Mi, d, c.ln_eps, stream))) return rc;
-    if ((rc = bd_gemm_bf16(h, lw.w_fc1, lw.b_fc1, ff, Mi, F, F, d, F, 1, stream))) return rc;
+    if (fused_ffn && lw.ffn_pack && lw.b_fc1_ln) {
+      // LayerNorm + fc1 + GELU + fc2 + residual in one kernel; the hidden activations stay on chip
+      if ((rc = bd_ffn_fused(x, x, lw.ffn_pack, lw.b_fc1_ln, lw.b_fc2, Mi, d, F, c.ln_eps, stream))) return rc;
+      continue;
+    }
+    if (pan_fc1 && lw.w_fc1_ln && lw.b_fc1_ln) {
+      if ((rc = bd_gemm_panel(x, lw.w_fc1_ln, lw.b_fc1_ln, ff, nullptr, Mi, F, d, F, 1, 1, c.ln_eps, stream))) return rc;
+    } else {
+      if ((rc = bd_layernorm(x, lw.ln2_g, lw.ln2_b, h, nullptr, nullptr, Mi, d, c.ln_eps, stream))) return rc;
+      if ((rc = bd_gemm_bf16(h, lw.w_fc1, lw.b_fc1, ff, Mi, F, F, d, F, 1, stream))) return rc;
+    }
     if ((rc = bd_gemm_bf16(ff, lw.w_fc2, lw.b_fc2, x, Mi, d, d, F, d, 2, stream))) return rc;
   }
   void* hf = hidden_out ? hidden_out : h;

@@ -60,6 +60,29 @@ int bd_layernorm(const float* x, const float* gamma, const float* beta, void* ou
 int bd_gemm_bf16(const void* A, const void* W, const float* bias, void* out, int M, int n_pad,
                  int n_real, int K, int ldc, int epilogue, void* stream);
 
+/* Row-panel GEMM for skinny-K layers: the 128-row activation panel lives in registers, only the
+ * weight stream goes through LDS; optional fused LayerNorm of A (fp32 rows; gamma / beta folded into
+ * W / bias by the caller). epilogue 0: bf16 = acc + bias; 1: bf16 = gelu(acc + bias); 2: fp32 out =
+ * resid + acc + bias (resid may alias out). bd_gemm_panel_supported tells whether (N, K) is handled
+ * (N % 128 == 0, K a multiple of 128 / 256 / 384 chunk; several chunks need N in {128, 384}).
+ * Same reference call sites as bd_gemm_bf16 (+ nn.LayerNorm, src/model/backbone.py:126,128). */
+int bd_gemm_panel_supported(int N, int K, int layernorm_a);
+int bd_gemm_panel(const void* A, const void* W, const float* bias, void* out, const float* resid, int M,
+                  int N, int K, int ldc, int epilogue, int layernorm_a, float eps, void* stream);
+
+/* Fused feed-forward block of one pre-norm layer, in place on the fp32 residual stream:
+ *     out = x + W2 * GELU(W1' * normalise(x) + b1') + b2        (x, out: fp32 [M, d]; may alias)
+ * normalise = LayerNorm without affine; the caller folds gamma into W1 (W1' = W1 * gamma) and beta
+ * into b1 (b1' = b1 + W1 * beta). The [M, F] hidden activations are never written to memory.
+ * wpack is the weight stream made by bd_ffn_pack_weights from W1' (bf16 [F, d]) and W2 (bf16 [d, F]);
+ * it holds bd_ffn_pack_bytes(d, F) bytes. Supported: d in {128, 256, 384}, F % 32 == 0, F <= 4096.
+ * Replaces TransformerBlock.forward's  x + ffn(ln2(x))  (src/model/backbone.py:128, FeedForward :85-96). */
+int bd_ffn_fused_supported(int d, int F);
+long bd_ffn_pack_bytes(int d, int F);
+int bd_ffn_pack_weights(const void* w1_folded, const void* w2, void* wpack, int d, int F, void* stream);
+int bd_ffn_fused(const float* x, float* out, const void* wpack, const float* b1_folded, const float* b2, int M,
+                 int d, int F, float eps, void* stream);
+
 /* Non-causal multi-head attention on the fused qkv rows [B*L, 3*H*head_dim] (bf16) with a
  * key-padding byte mask [B,L] (non-zero = visible; null = all visible). A query whose keys
  * are all masked gives an all-zero output row. out [B*L, H*head_dim] bf16; lse optional
@@ -80,6 +103,13 @@ typedef struct bd_layer_weights {
   const float* ln2_g; const float* ln2_b;
   const void* w_fc1;  const float* b_fc1;   /* [F, d],  [F]            */
   const void* w_fc2;  const float* b_fc2;   /* [d, F],  [d]            */
+  /* optional LayerNorm-folded copies for the fused path (null = unfused):
+   * w' = w * gamma (per input column), b' = b + w * beta                 */
+  const void* w_qkv_ln; const float* b_qkv_ln;
+  const void* w_fc1_ln; const float* b_fc1_ln;
+  /* optional weight stream of the fused feed-forward kernel (bd_ffn_pack_weights of w_fc1_ln and
+   * w_fc2; needs b_fc1_ln); null = separate fc1 / fc2 GEMMs                                   */
+  const void* ffn_pack;
 } bd_layer_weights;
 
 typedef struct bd_backbone_desc {

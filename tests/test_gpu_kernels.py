@@ -172,3 +172,148 @@ def test_bad_arguments_are_rejected(gpu_device):
     assert b"multiple" in lib.bd_last_error()
     assert lib.bd_attention_fwd(_lib.ptr(a), None, _lib.ptr(a), None, 1, 8, 1, 48, _s()) < 0
     assert lib.bd_gemm_bf16(None, _lib.ptr(a), None, _lib.ptr(a), 8, 128, 128, 64, 128, 0, _s()) < 0
+
+
+def panel(A, W, bias, out, resid, epi, ln):
+    M, K = A.shape
+    N = W.shape[0]
+    rc = _lib.lib().bd_gemm_panel(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(resid), M, N, K,
+                                  out.shape[1], epi, int(ln), 1e-5, _s())
+    _lib.check(rc, "panel gemm")
+    torch.cuda.synchronize()
+
+
+def test_panel_gemm_layout_exact_integers(gpu_device):
+    dev = gpu_device
+    g = torch.Generator().manual_seed(0)
+    for (M, N, K) in [(200, 384, 384), (130, 128, 256), (77, 384, 1536), (300, 1152, 384)]:
+        A = torch.randint(-3, 4, (M, K), generator=g).float()
+        W = torch.randint(-3, 4, (N, K), generator=g).float()
+        bias = torch.randint(-5, 6, (N,), generator=g).float()
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        panel(A.to(dev).bfloat16(), W.to(dev).bfloat16(), bias.to(dev), out, None, 0, False)
+        assert torch.equal(out.float().cpu(), (A @ W.t() + bias).bfloat16().float()), (M, N, K)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (300, 384, 384), (1000, 1152, 384), (257, 384, 1536),
+                                   (64, 1536, 384), (4096, 384, 384), (500, 128, 256), (333, 256, 128),
+                                   (700, 768, 768), (200, 128, 768), (150, 384, 256)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_panel_gemm_epilogues(gpu_device, M, N, K, epi):
+    dev = gpu_device
+    assert _lib.lib().bd_gemm_panel_supported(N, K, 0) == 1
+    g = torch.Generator().manual_seed(M + N + K + epi)
+    A = (torch.randn(M, K, generator=g) * 0.7).bfloat16()
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16()
+    bias = torch.randn(N, generator=g) * 0.3
+    acc = A.float() @ W.float().t() + bias
+    if epi == 2:
+        x0 = torch.randn(M, N, generator=g)
+        out = x0.clone().to(dev)
+        ref = x0 + acc
+        panel(A.to(dev), W.to(dev), bias.to(dev), out, out, 2, False)
+    else:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        ref = acc if epi == 0 else torch.nn.functional.gelu(acc)
+        panel(A.to(dev), W.to(dev), bias.to(dev), out, None, epi, False)
+    tol = 2e-2 if epi != 2 else 1e-4
+    assert (out.float().cpu() - ref).abs().max().item() / ref.abs().max().item() < tol
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 1152, 384), (129, 1536, 384), (70, 384, 128), (512, 256, 256)])
+@pytest.mark.parametrize("epi", [0, 1])
+def test_panel_gemm_fused_layernorm(gpu_device, M, N, K, epi):
+    """LN(x) W^T + b with gamma / beta folded into the weights on the host."""
+    dev = gpu_device
+    assert _lib.lib().bd_gemm_panel_supported(N, K, 1) == 1
+    g = torch.Generator().manual_seed(M + N + K + epi)
+    x = torch.randn(M, K, generator=g) * 2 + 0.7
+    gm = 1 + 0.2 * torch.randn(K, generator=g)
+    bt = 0.3 * torch.randn(K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g) * 0.3
+    ref = torch.nn.functional.layer_norm(x, (K,), gm, bt, 1e-5) @ W.t() + bias
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    Wf = (W * gm[None, :]).bfloat16()
+    bf = bias + W @ bt
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    panel(x.to(dev), Wf.to(dev), bf.to(dev), out, None, epi, True)
+    assert (out.float().cpu() - ref).abs().max().item() / ref.abs().max().item() < 2e-2
+
+
+def test_panel_gemm_unsupported_shapes_are_reported(gpu_device):
+    lib = _lib.lib()
+    assert lib.bd_gemm_panel_supported(256, 768, 0) == 0      # K in several chunks needs N = 128 or a multiple of 384
+    assert lib.bd_gemm_panel_supported(768, 768, 0) == 1
+    assert lib.bd_gemm_panel_supported(1152, 768, 1) == 0     # fused LayerNorm needs a single chunk
+    assert lib.bd_gemm_panel_supported(100, 384, 0) == 0
+    a = torch.zeros(256, 768, dtype=torch.bfloat16, device=gpu_device)
+    assert lib.bd_gemm_panel(_lib.ptr(a), _lib.ptr(a), None, _lib.ptr(a), None, 8, 256, 768, 256, 0, 0, 1e-5, _s()) < 0
+
+
+# ---------------------------------------------------------------- fused feed-forward block
+def _ffn_case(gpu_device, M, d, F, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, d, generator=g) * 1.5 + 0.3
+    gm = 1 + 0.2 * torch.randn(d, generator=g)
+    bt = 0.3 * torch.randn(d, generator=g)
+    W1 = torch.randn(F, d, generator=g) / math.sqrt(d)
+    b1 = 0.3 * torch.randn(F, generator=g)
+    W2 = torch.randn(d, F, generator=g) / math.sqrt(F)
+    b2 = 0.3 * torch.randn(d, generator=g)
+    lib = _lib.lib()
+    w1f = (W1 * gm).bfloat16().to(gpu_device)
+    w2b = W2.bfloat16().to(gpu_device)
+    b1f = (b1 + W1 @ bt).to(gpu_device)
+    b2d = b2.to(gpu_device)
+    pack = torch.empty(lib.bd_ffn_pack_bytes(d, F), dtype=torch.uint8, device=gpu_device)
+    _lib.check(lib.bd_ffn_pack_weights(_lib.ptr(w1f), _lib.ptr(w2b), _lib.ptr(pack), d, F, _s()), "pack")
+    xd = x.to(gpu_device)
+    out = torch.empty_like(xd)
+    _lib.check(lib.bd_ffn_fused(_lib.ptr(xd), _lib.ptr(out), _lib.ptr(pack), _lib.ptr(b1f), _lib.ptr(b2d), M, d, F,
+                                1e-5, _s()), "ffn")
+    torch.cuda.synchronize()
+    # fp32 reference of the module chain: x + fc2(gelu(fc1(LayerNorm(x))))
+    ref = x + torch.nn.functional.gelu(torch.nn.functional.layer_norm(x, (d,), gm, bt, 1e-5) @ W1.t() + b1) @ W2.t() + b2
+    return out.cpu(), ref, (xd, pack, b1f, b2d)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,d,F", [(128, 384, 1536), (300, 384, 1536), (1, 384, 1536), (257, 256, 1024),
+                                   (1000, 128, 512), (64, 128, 96), (4096, 384, 1536)])
+def test_ffn_fused_matches_fp32_reference(gpu_device, M, d, F):
+    assert _lib.lib().bd_ffn_fused_supported(d, F) == 1
+    out, ref, _ = _ffn_case(gpu_device, M, d, F, seed=M + d + F)
+    # bf16 operands (LayerNorm output, weights, hidden activations), fp32 accumulation and residual
+    err = (out - ref).abs().max().item()
+    assert err < 2e-2 * ref.abs().max().item(), err
+    assert torch.isfinite(out).all()
+
+
+@pytest.mark.gpu
+def test_ffn_fused_in_place_and_rows_independent(gpu_device):
+    M, d, F = 300, 384, 1536
+    out, _, (xd, pack, b1f, b2d) = _ffn_case(gpu_device, M, d, F, seed=5)
+    lib = _lib.lib()
+    x2 = xd.clone()
+    _lib.check(lib.bd_ffn_fused(_lib.ptr(x2), _lib.ptr(x2), _lib.ptr(pack), _lib.ptr(b1f), _lib.ptr(b2d), M, d, F, 1e-5,
+                                _s()), "ffn in place")
+    torch.cuda.synchronize()
+    assert torch.equal(x2.cpu(), out)                       # aliasing out == x gives the same bits
+    sub = xd[37:38].clone()
+    o1 = torch.empty_like(sub)
+    _lib.check(lib.bd_ffn_fused(_lib.ptr(sub), _lib.ptr(o1), _lib.ptr(pack), _lib.ptr(b1f), _lib.ptr(b2d), 1, d, F, 1e-5,
+                                _s()), "ffn one row")
+    torch.cuda.synchronize()
+    assert torch.equal(o1.cpu()[0], out[37])                # a row does not depend on its panel mates
+
+
+@pytest.mark.gpu
+def test_ffn_fused_unsupported_shapes_are_refused(gpu_device):
+    lib = _lib.lib()
+    assert lib.bd_ffn_fused_supported(512, 2048) == 0
+    assert lib.bd_ffn_fused_supported(384, 1000) == 0
+    assert lib.bd_ffn_fused_supported(384, 64) == 0
+    a = torch.zeros(1024, device=gpu_device)
+    assert lib.bd_ffn_fused(_lib.ptr(a), _lib.ptr(a), _lib.ptr(a), _lib.ptr(a), _lib.ptr(a), 2, 512, 2048, 1e-5, _s()) < 0
