@@ -3,25 +3,23 @@
 // in ONE kernel that reads the fp32 residual stream once and writes it once. The hidden
 // activations ([tokens, F], the largest tensor of the layer) never exist in memory.
 //
-// A 256-thread workgroup owns 128 tokens, each wave 32 of them. Everything a wave needs of its
-// tokens lives in registers for the whole kernel:
-//   * the residual rows as MFMA accumulators  acc[n-tile][token-tile]  (fp32, 16x16 tiles with
-//     the TOKEN as the MFMA column), initialised from x and accumulated into by the second GEMM,
+// A 256-thread workgroup owns 128 tokens, each wave 32 of them (one 32-wide MFMA column block).
+// Everything a wave needs of its tokens lives in registers for the whole kernel:
+//   * the residual rows as MFMA accumulators acc[T] (fp32 32x32 tiles, the TOKEN is the MFMA
+//     column), initialised from x and accumulated into by the second GEMM,
 //   * LayerNorm(x) as bf16 MFMA B operands, built from those same registers.
-// The weights are the MFMA A operands. They are streamed through a three-buffer LDS ring with
+// The weights are the MFMA A operands. They are streamed through a six-unit LDS ring with
 // LDS-DMA loads from a stream the host packed in fragment order (bd_ffn_pack_weights): one
 // wave-instruction moves 1 KiB that is, byte for byte, the 64 lanes' A fragment of one MFMA, so
 // global reads are whole lines and LDS reads are conflict-free without any swizzle.
 //
-// Chaining without data movement: a 16x16 MFMA result holds, for token column c, rows 4g..4g+3
-// (g = lane / 16); the next MFMA wants, for the same column, k = 8g..8g+7. Because the weight
-// fragments are packed by the host, the row order of W1 tiles and the k order of both GEMMs are
-// free: the packing is chosen so that two result tiles, converted to bf16, ARE the next B operand.
-// The hidden layer is walked in chunks of 32 units: GEMM1 (2 tiles x d/32 k-blocks), GELU in
-// registers, GEMM2 (d/16 tiles x 1 k-block) into the residual accumulators.
+// Chaining without data movement: because the weight fragments are packed by the host, the k
+// order of both GEMMs is free, and it is chosen so that a result tile, rounded to bf16, IS the
+// next GEMM's B operand (details at the kernel). The hidden layer is walked in chunks of 32
+// units: GEMM1 (d/16 MFMAs), GELU in registers, GEMM2 (d/16 MFMAs) into the residual accumulators.
 #include "bd_common.h"
 #include "bd_prof.h"
-#include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -36,55 +34,48 @@ struct FfnArgs {
   const float* b2;              // [d]
   int M, F;
   float eps;
+  int stagger_blocks;           // workgroups of the first round (= CUs), which start phase-shifted
+  int stagger_units;            // phase step in units of ~1 us
 };
 
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-
+// 32x32x16 MFMAs: such an MFMA keeps the SIMD's vector issue port for 8 of its 32 cycles (a
+// 16x16x32 one for 8 of 16), which leaves room for the GELU arithmetic, the LDS reads and the
+// LDS-DMA issue of a wave that is alone on its SIMD. Layouts (h = lane / 32, c = lane % 32):
+//   A operand: row c, k = 8 h + e          B operand: column c, k = 8 h + e        (e = 0..7)
+//   D: column c, row 8 (r / 4) + 4 h + r % 4                                        (r = 0..15)
+// acc[T][r] = x[token c][32 T + 8 (r / 4) + 4 h + r % 4]; registers 8 kk .. 8 kk + 7 of a D tile
+// (kk = 0, 1), rounded to bf16, are the B operand of k-block kk of that tile for the next GEMM
+// when the weight fragments use the k order  e -> 8 (2 kk + e / 4) + 4 h + e % 4  (the packing).
+// The GELU of chunk j + 1 is spread over GEMM2 of chunk j (first half of the values) and GEMM1 of
+// chunk j + 2 (second half), about five scalar instructions per MFMA.
+//
 // GELU(x) = x * clamp(0.5 + x P(min(x^2, 16)), 0, 1): x P(x^2) is a degree-7 minimax fit of
 // 0.5 erf(x / sqrt 2) on |x| <= 4; past that the product overshoots +-0.5 and the clamp saturates
 // it. |error| < 2e-4 absolute, below the bf16 rounding of the activations that matter. No
 // transcendental and only scalar fp32 FMAs (packed fp32 math is slow next to MFMAs).
-// Evaluated for two values at a time in three parts, so the chains can be spread between MFMAs.
-struct GeluState { float x0, x1, s0, s1, p0, p1; };
-__device__ __forceinline__ void gelu_part0(GeluState& g, float a, float b) {
-  g.x0 = a; g.x1 = b;
-  g.s0 = fminf(a * a, 16.0f); g.s1 = fminf(b * b, 16.0f);
-  g.p0 = g.s0 * -1.903182666e-09f + 1.410586241e-07f; g.p1 = g.s1 * -1.903182666e-09f + 1.410586241e-07f;
-  g.p0 = g.p0 * g.s0 + -4.565313249e-06f;             g.p1 = g.p1 * g.s1 + -4.565313249e-06f;
-}
-__device__ __forceinline__ void gelu_part1(GeluState& g) {
-  g.p0 = g.p0 * g.s0 + 8.634553992e-05f;  g.p1 = g.p1 * g.s1 + 8.634553992e-05f;
-  g.p0 = g.p0 * g.s0 + -1.085383136e-03f; g.p1 = g.p1 * g.s1 + -1.085383136e-03f;
-  g.p0 = g.p0 * g.s0 + 9.789848745e-03f;  g.p1 = g.p1 * g.s1 + 9.789848745e-03f;
-}
-__device__ __forceinline__ f32x2 gelu_part2(GeluState& g) {
-  g.p0 = g.p0 * g.s0 + -6.636063135e-02f; g.p1 = g.p1 * g.s1 + -6.636063135e-02f;
-  g.p0 = g.p0 * g.s0 + 3.989269649e-01f;  g.p1 = g.p1 * g.s1 + 3.989269649e-01f;
-  const float t0 = __builtin_amdgcn_fmed3f(g.x0 * g.p0 + 0.5f, 0.0f, 1.0f);
-  const float t1 = __builtin_amdgcn_fmed3f(g.x1 * g.p1 + 0.5f, 0.0f, 1.0f);
-  return (f32x2){g.x0 * t0, g.x1 * t1};
-}
+struct Gelu2 { float x0, x1, s0, s1, p0, p1; };
 
-template <int NT, int DBG = 0>  // NT = d / 16 output tiles; d / 32 = NT / 2 k-blocks; DBG: timing ablations
+template <int NT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void ffn_fused_kernel(FfnArgs p) {
   constexpr int D = NT * 16;
-  constexpr int NKB = NT / 2;
-  constexpr int MT = 2;                       // 16-token tiles per wave
-  // The stream is a sequence of units of NT fragments (1 KiB each): unit 2 j = W1 of chunk j
-  // (2 tiles x NKB k-blocks), unit 2 j + 1 = W2 of chunk j (NT tiles). The LDS ring holds six
-  // units: byte o of the stream lives at o mod (6 units).
-  constexpr int UNIT = NT * 1024;
+  constexpr int NT32 = NT / 2;                // 32-feature tiles of the residual row
+  constexpr int UNIT = NT * 1024;             // unit 2 j = W1 of chunk j, unit 2 j + 1 = W2 of chunk j
   constexpr int RING = 6;
-  constexpr int PER_UNIT = NT / 4;            // LDS-DMA instructions per wave and unit
-  static_assert(NT % 4 == 0, "fragments must split evenly over the four waves");
+  constexpr int PER_UNIT = NT / 4;
+  constexpr int NF = 2 * NT;                  // fragments (= MFMAs) per chunk
+  constexpr int FB = 8;                       // fragment read batch
+  static_assert(NT % FB == 0, "fragment batches must tile both GEMMs");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   float* const sb1 = (float*)(smem + RING * UNIT);     // F + 32 floats
+  typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
+  typedef const __attribute__((address_space(3))) f32x4* lds_f4;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = lane >> 4, c = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: LDS-DMA targets stay scalar
+  const int h = lane >> 5, c = lane & 31;
   const int nch = p.F >> 5;
   const int nunits = 2 * nch;
-  const int m0 = blockIdx.x * 128 + wave * 32;
+  const int m = blockIdx.x * 128 + wave * 32 + c;
 
   auto issue_unit = [&](int u) {
     const unsigned char* src = p.wpack + (size_t)u * UNIT + lane * 16;
@@ -96,136 +87,163 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
   };
 
-  // ---- residual rows -> accumulators: lane (g, c) holds x[token c of tile mt][16 nt + 4 g + r]
-  f32x4 acc[NT][MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int m = m0 + 16 * mt + c;
-    const int row = m < p.M ? m : p.M - 1;
-    const float* xr = p.x + (size_t)row * D + 4 * g;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = *(const f32x4*)(xr + 16 * nt);
+  // The first workgroup of every CU starts a little later than its neighbours' (16 phases): all
+  // workgroups take the same time, so without this every CU would load its rows, compute and
+  // store in lockstep, and the memory system would alternate between overload and idleness.
+  if ((int)blockIdx.x < p.stagger_blocks) {
+    const int phase = (blockIdx.x >> 3) & 15;
+    for (int k = 0; k < phase * p.stagger_units; ++k) __builtin_amdgcn_s_sleep(32);
   }
-  // the first five units start flowing (F >= 96 is checked by the host, so they all exist)
-#pragma unroll
-  for (int u = 0; u < 5; ++u) issue_unit(u);
 
+  f32x16 acc[NT32];
+  {
+    const float* xr = p.x + (size_t)(m < p.M ? m : p.M - 1) * D + 4 * h;
+#pragma unroll
+    for (int T = 0; T < NT32; ++T)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *(const f32x4*)(xr + 32 * T + 8 * q);
+        acc[T][4 * q + 0] = v[0]; acc[T][4 * q + 1] = v[1]; acc[T][4 * q + 2] = v[2]; acc[T][4 * q + 3] = v[3];
+      }
+  }
+#pragma unroll
+  for (int u = 0; u < 5; ++u) issue_unit(u);            // F >= 96: the first five units exist
   for (int i = tid; i < p.F + 32; i += 256) sb1[i] = i < p.F ? p.b1[i] : 0.f;
 
-  // ---- LayerNorm (gamma / beta live in the packed W1 and in b1) -> bf16 B operands
-  bf16x8 xln[NKB][MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
+  // ---- LayerNorm -> bf16 B operands (gamma / beta are folded into W1 and b1)
+  bf16x8 xln[NT];
+  {
     float s = 0.f;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) s += (acc[nt][mt][0] + acc[nt][mt][1]) + (acc[nt][mt][2] + acc[nt][mt][3]);
-    s += __shfl_xor(s, 16, 64);
+    for (int T = 0; T < NT32; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[T][r];
     s += __shfl_xor(s, 32, 64);
     const float mean = s * (1.0f / D);
     float q = 0.f;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int T = 0; T < NT32; ++T)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const float dv = acc[nt][mt][r] - mean; q += dv * dv; }
-    q += __shfl_xor(q, 16, 64);
+      for (int r = 0; r < 16; ++r) { const float dv = acc[T][r] - mean; q += dv * dv; }
     q += __shfl_xor(q, 32, 64);
     const float rstd = rsqrtf(q * (1.0f / D) + p.eps);
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
+    for (int kb = 0; kb < NT; ++kb) {
       bf16x8 f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        f[r] = (__bf16)((acc[2 * kb][mt][r] - mean) * rstd);
-        f[4 + r] = (__bf16)((acc[2 * kb + 1][mt][r] - mean) * rstd);
-      }
-      xln[kb][mt] = f;
+      for (int e = 0; e < 8; ++e) f[e] = (__bf16)((acc[kb >> 1][8 * (kb & 1) + e] - mean) * rstd);
+      xln[kb] = f;
     }
   }
 
-  // One chunk step = GEMM1 of chunk j1 (24 W1 fragments) followed by GEMM2 of chunk j1 - 1 (24 W2
-  // fragments, B operand hb) with the GELU of GEMM1's result spread between GEMM2's MFMAs.
-  // Fragment reads run LOOK fragments ahead of their MFMAs; the sched_group_barrier sequence at
-  // the end pins that interleave (1 LDS read, 2 MFMA, a few VALU per fragment).
-  // Fragment reads are batched: while the MFMAs of one batch of FB fragments run, the reads of the
-  // next batch are issued during the FIRST half of it, so that by the time the compiler's
-  // wait-for-all (it does not count LDS reads individually here) comes up at the next batch, the
-  // youngest read is half a batch old and the one wave of a SIMD does not stall on it.
-  constexpr int FB = 8;
-  constexpr int NF = 2 * NT;                  // fragments per step
-  static_assert(NT % FB == 0, "batches must not straddle the two GEMMs' prologue-only case");
-  typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
-  typedef const __attribute__((address_space(3))) f32x4* lds_f4;
-  auto frag_off = [&](int i) -> int {
-    // GEMM1 order: k-block major, tile minor, so the four accumulators are hit round robin
-    return i < NT ? ((i & 1) * NKB + (i >> 1)) * 1024 : (i - NT) * 1024;
-  };
   const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem + lane * 16;
-  const unsigned ldsb = (unsigned)(size_t)(lds_void*)sb1 + 32 * g;
-  auto chunk_step = [&](int j1, bool do_gemm2, bf16x8 (&hb)[MT]) {
-    // unit bases as opaque registers, so every fragment read is base + 16-bit immediate
+  const unsigned ldsb = (unsigned)(size_t)(lds_void*)sb1 + 16 * h;
+
+  f32x16 hn_cur, hn_next;      // GEMM1 results of chunk j and j + 1 (rows = hidden units of the chunk)
+  bf16x8 hb[2], hb0_next;      // GELU(hn_cur) as the two B operands of GEMM2; first half of the next
+  Gelu2 gs;
+
+  // GELU part g (0..47): pair g / 6 = registers 2 pair, 2 pair + 1 of the source tile, in six parts
+  auto gelu_part = [&](int g, const f32x16& src, bf16x8& dst) {
+    const int pair = g / 6, part = g % 6;
+    if (part == 0) {
+      gs.x0 = src[2 * pair]; gs.x1 = src[2 * pair + 1];
+      gs.s0 = fminf(gs.x0 * gs.x0, 16.0f); gs.s1 = fminf(gs.x1 * gs.x1, 16.0f);
+      asm volatile("" : "+v"(gs.s0), "+v"(gs.s1));
+    } else if (part == 1) {
+      gs.p0 = gs.s0 * -1.903182666e-09f + 1.410586241e-07f; gs.p1 = gs.s1 * -1.903182666e-09f + 1.410586241e-07f;
+      gs.p0 = gs.p0 * gs.s0 + -4.565313249e-06f;            gs.p1 = gs.p1 * gs.s1 + -4.565313249e-06f;
+      asm volatile("" : "+v"(gs.p0), "+v"(gs.p1));
+    } else if (part == 2) {
+      gs.p0 = gs.p0 * gs.s0 + 8.634553992e-05f;  gs.p1 = gs.p1 * gs.s1 + 8.634553992e-05f;
+      gs.p0 = gs.p0 * gs.s0 + -1.085383136e-03f; gs.p1 = gs.p1 * gs.s1 + -1.085383136e-03f;
+      asm volatile("" : "+v"(gs.p0), "+v"(gs.p1));
+    } else if (part == 3) {
+      gs.p0 = gs.p0 * gs.s0 + 9.789848745e-03f;  gs.p1 = gs.p1 * gs.s1 + 9.789848745e-03f;
+      gs.p0 = gs.p0 * gs.s0 + -6.636063135e-02f; gs.p1 = gs.p1 * gs.s1 + -6.636063135e-02f;
+      asm volatile("" : "+v"(gs.p0), "+v"(gs.p1));
+    } else if (part == 4) {
+      gs.p0 = gs.p0 * gs.s0 + 3.989269649e-01f;  gs.p1 = gs.p1 * gs.s1 + 3.989269649e-01f;
+      gs.p0 = __builtin_amdgcn_fmed3f(gs.x0 * gs.p0 + 0.5f, 0.0f, 1.0f);
+      gs.p1 = __builtin_amdgcn_fmed3f(gs.x1 * gs.p1 + 0.5f, 0.0f, 1.0f);
+      asm volatile("" : "+v"(gs.p0), "+v"(gs.p1));
+    } else {
+      const int j0 = 4 * ((pair >> 1) & 1) + 2 * (pair & 1);
+      dst[j0] = (__bf16)(gs.x0 * gs.p0);
+      dst[j0 + 1] = (__bf16)(gs.x1 * gs.p1);
+      asm volatile("" : "+v"(dst));
+    }
+  };
+
+  // One chunk iteration: GEMM1 of chunk j1 into hn_next, then (unless first) GEMM2 of chunk j1 - 1
+  // from hb. Fragment i < NT is W1 k-block i, fragment NT + 2 T + kk is W2 tile T, k-block kk.
+  // A wave alone on its SIMD must never drain its LDS queue: the fragment reads run LOOK ahead of
+  // their MFMAs and every MFMA waits with an exact count. The compiler only places
+  // wait-for-everything on LDS reads here, so the steady-state path issues its reads and waits as
+  // inline asm (ASM_READS); the one-off first step keeps compiler-managed loads.
+  constexpr int LOOK = 8;
+  auto chunk_step = [&](int j1, auto first_tag) {
+    constexpr bool first = decltype(first_tag)::value;
+    constexpr bool ASM_READS = !first;
     unsigned W1b = lds0 + ((2 * j1) % RING) * UNIT;
     unsigned W2b = lds0 + ((2 * j1 + RING - 1) % RING) * UNIT;
     unsigned bb1 = ldsb + 128 * j1;
     asm volatile("" : "+v"(W1b), "+v"(W2b), "+v"(bb1));
-    const int nf = do_gemm2 ? NF : NT;
-    auto read_frag = [&](int i) -> bf16x8 { return *(lds_frag)(size_t)((i < NT ? W1b : W2b) + frag_off(i)); };
-    const f32x4 bia0 = *(lds_f4)(size_t)bb1, bia1 = *(lds_f4)(size_t)(bb1 + 16);
+    constexpr int nf = first ? NT : NF;
     bf16x8 wf[NF];
-    bf16x8 hnew[MT];
-    GeluState gs;
-    if (DBG & 4) { hnew[0] = hb[0]; hnew[1] = hb[1]; }
+    auto read_frag = [&](int i) {
+      if (ASM_READS) {
+        if (i < NT) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[i]) : "v"(W1b), "i"(i * 1024));
+        else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[i]) : "v"(W2b), "i"((i - NT) * 1024));
+      } else {
+        wf[i] = *(lds_frag)(size_t)(i < NT ? W1b + i * 1024 : W2b + (i - NT) * 1024);
+      }
+    };
+    // bias first (oldest in the queue), then the first LOOK fragments
+    f32x4 bq[4];
 #pragma unroll
-    for (int i = 0; i < FB; ++i) wf[i] = read_frag(i);
-    f32x4 hn[2][MT];
+    for (int q = 0; q < 4; ++q) {
+      if (ASM_READS) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[q]) : "v"(bb1), "i"(32 * q));
+      else bq[q] = *(lds_f4)(size_t)(bb1 + 32 * q);
+    }
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) { hn[0][mt] = bia0; hn[1][mt] = bia1; }
+    for (int i = 0; i < LOOK; ++i) read_frag(i);
+    if (ASM_READS) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]) : "i"(LOOK));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      hn_next[4 * q + 0] = bq[q][0]; hn_next[4 * q + 1] = bq[q][1]; hn_next[4 * q + 2] = bq[q][2]; hn_next[4 * q + 3] = bq[q][3];
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
       if (i < nf) {
-        const int q = i % FB, nb = (i / FB + 1) * FB;     // position in the batch, start of the next
-        if (q < FB / 2 && nb < nf) {
-          wf[nb + 2 * q] = read_frag(nb + 2 * q);
-          wf[nb + 2 * q + 1] = read_frag(nb + 2 * q + 1);
-        }
+        if (i + LOOK < nf) read_frag(i + LOOK);
+        // reads younger than fragment i that may stay in flight
+        if (ASM_READS) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(wf[i]) : "i"(i + LOOK < nf ? LOOK : nf - 1 - i));
         if (i < NT) {
-          const int kb = i >> 1, t = i & 1;
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            if (!(DBG & 16)) hn[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xln[kb][mt], hn[t][mt], 0, 0, 0);
-            else asm volatile("" :: "v"(wf[i]));
+          hn_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xln[i], hn_next, 0, 0, 0);
         } else {
-          const int nt = i - NT;
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            if (!(DBG & 8)) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], hb[mt], acc[nt][mt], 0, 0, 0);
-            else asm volatile("" :: "v"(wf[i]));
+          const int T = (i - NT) >> 1, kk = (i - NT) & 1;
+          acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], hb[kk], acc[T], 0, 0, 0);
         }
       }
-      // GELU piece k = (mt, t, r2), two values, in three parts on consecutive fragments; the two
-      // result tiles are, lane for lane, the k = 8 g + (4 t + r) B operand of GEMM2. The pieces
-      // sit beside GEMM2's MFMAs when there is a GEMM2.
-      if (i >= NT && !(DBG & 4)) {
+      {
+        if (i < NT) {
+          // second half of GELU(hn_cur) -> hb[1], beside GEMM1 (skipped before the first chunk)
+          if (!first) {
 #pragma unroll
-        for (int slot = (i - NT) * 24 / NT; slot < (i - NT + 1) * 24 / NT; ++slot) {
-          const int k = slot / 3, part = slot % 3, mt = k >> 2, t = (k >> 1) & 1, r2 = k & 1;
-          // the empty asm statements tie each part to its fragment step (plain arithmetic would
-          // otherwise drift to the end of the block, behind all the MFMAs)
-          if (part == 0) { gelu_part0(gs, hn[t][mt][2 * r2], hn[t][mt][2 * r2 + 1]); asm volatile("" : "+v"(gs.p0), "+v"(gs.p1)); }
-          if (part == 1) { gelu_part1(gs); asm volatile("" : "+v"(gs.p0), "+v"(gs.p1)); }
-          if (part == 2) {
-            const f32x2 v = gelu_part2(gs);
-            hnew[mt][4 * t + 2 * r2] = (__bf16)v[0];
-            hnew[mt][4 * t + 2 * r2 + 1] = (__bf16)v[1];
-            asm volatile("" : "+v"(hnew[mt]));
+            for (int g = 24 + i * 24 / NT; g < 24 + (i + 1) * 24 / NT; ++g) gelu_part(g, hn_cur, hb[1]);
           }
+        } else {
+          // first half of GELU(hn_next) -> hb0_next, beside GEMM2 (or alone before the first chunk)
+#pragma unroll
+          for (int g = (i - NT) * 24 / NT; g < (i - NT + 1) * 24 / NT; ++g) gelu_part(g, hn_next, hb0_next);
         }
       }
       __builtin_amdgcn_sched_barrier(0);     // nothing moves between fragment steps
     }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) hb[mt] = hnew[mt];
-    // keeps the activation in this step (it would otherwise sink below the barrier that follows)
+    hn_cur = hn_next;
+    hb[0] = hb0_next;
     asm volatile("" : "+v"(hb[0]), "+v"(hb[1]));
   };
 
@@ -234,26 +252,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  bf16x8 hb[MT];
-  chunk_step(0, false, hb);
+  hb[1] = xln[0];                    // defined value; overwritten before its first real use
+  chunk_step(0, std::true_type{});
 
-  for (int j = 0; j < ((DBG & 32) ? 0 : nch); ++j) {
+  for (int j = 0; j < nch; ++j) {
     // units 2 j + 5 and 2 j + 6 go where units 2 j - 1 and 2 j were read during iteration j - 1
     const int u5 = 2 * j + 5;
-    if (!(DBG & 1)) {
     if (u5 < nunits) issue_unit(u5);
     if (u5 + 1 < nunits) issue_unit(u5 + 1);
-    }
-
-    // GEMM1 of chunk j + 1 (past the end: a stale unit and zero biases, result unused), GEMM2 of
-    // chunk j
-    chunk_step(j + 1, true, hb);
-
+    // GEMM1 of chunk j + 1 (past the end: a stale unit and zero biases, result unused), GEMM2 of chunk j
+    chunk_step(j + 1, std::false_type{});
     // units 2 j + 3 and 2 j + 4 (issued one iteration ago) must have landed for every wave before
     // the next iteration reads them; what this iteration issued stays in flight
-    if (DBG & 2) continue;
-    if ((DBG & 1)) {}
-    else if (u5 + 1 < nunits) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_UNIT) : "memory");
+    if (u5 + 1 < nunits) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_UNIT) : "memory");
     else if (u5 < nunits) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_UNIT) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -261,46 +272,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 
   // ---- epilogue: + b2, store the new residual rows
-  f32x4 bb[NT];
+  if (m < p.M) {
+    float* o = p.out + (size_t)m * D + 4 * h;
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) bb[nt] = *(const f32x4*)(p.b2 + 16 * nt + 4 * g);
+    for (int T = 0; T < NT32; ++T)
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int m = m0 + 16 * mt + c;
-    if (m < p.M) {
-      float* o = p.out + (size_t)m * D + 4 * g;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        f32x4 v = acc[nt][mt];
-        v[0] += bb[nt][0]; v[1] += bb[nt][1]; v[2] += bb[nt][2]; v[3] += bb[nt][3];
-        *(f32x4*)(o + 16 * nt) = v;
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b = *(const f32x4*)(p.b2 + 32 * T + 8 * q + 4 * h);
+        f32x4 v;
+        v[0] = acc[T][4 * q + 0] + b[0]; v[1] = acc[T][4 * q + 1] + b[1];
+        v[2] = acc[T][4 * q + 2] + b[2]; v[3] = acc[T][4 * q + 3] + b[3];
+        *(f32x4*)(o + 32 * T + 8 * q) = v;
       }
-    }
   }
 }
 
 // Packs W1 (LayerNorm gamma already folded, bf16 [F, d]) and W2 (bf16 [d, F]) into the fragment
-// stream: chunk j = 32 hidden units; fragment = 64 lanes x 8 bf16.
-//   W1 fragment (t, kb), lane (c, g), element e:  W1[32 j + 8 (c / 4) + 4 t + c % 4][16 (2 kb + e / 4) + 4 g + e % 4]
-//   W2 fragment nt,      lane (c, g), element e:  W2[16 nt + c][32 j + 8 g + e]
+// stream of ffn_fused_kernel: chunk j = 32 hidden units; fragment = 64 lanes x 8 bf16, lane = 32 h + c.
+//   W1 fragment kb (16 features), element e:  W1[32 j + c][32 (kb / 2) + 8 (2 (kb % 2) + e / 4) + 4 h + e % 4]
+//   W2 fragment 2 T + kk,         element e:  W2[32 T + c][32 j + 8 (2 kk + e / 4) + 4 h + e % 4]
 __global__ void ffn_pack_kernel(const unsigned short* __restrict__ w1, const unsigned short* __restrict__ w2,
                                 unsigned short* __restrict__ out, int d, int F) {
-  const int NT = d / 16, NKB = NT / 2, FRAGS = 2 * NT;
+  const int NT = d / 16, FRAGS = 2 * NT;
   const long total = (long)(F / 32) * FRAGS * 512;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int e = i & 7, l = (i >> 3) & 63;
-    const int c = l & 15, g = l >> 4;
+    const int c = l & 31, h = l >> 5;
     const long fr = i >> 9;
     const int f = fr % FRAGS, j = fr / FRAGS;
     unsigned short v;
-    if (f < 2 * NKB) {
-      const int t = f / NKB, kb = f % NKB;
-      const int u = 32 * j + 8 * (c >> 2) + 4 * t + (c & 3);
-      const int k = 16 * (2 * kb + (e >> 2)) + 4 * g + (e & 3);
-      v = w1[(size_t)u * d + k];
+    if (f < NT) {
+      const int kb = f;
+      const int k = 32 * (kb >> 1) + 8 * (2 * (kb & 1) + (e >> 2)) + 4 * h + (e & 3);
+      v = w1[(size_t)(32 * j + c) * d + k];
     } else {
-      const int nt = f - 2 * NKB;
-      v = w2[(size_t)(16 * nt + c) * F + 32 * j + 8 * g + e];
+      const int T = (f - NT) >> 1, kk = (f - NT) & 1;
+      v = w2[(size_t)(32 * T + c) * F + 32 * j + 8 * (2 * kk + (e >> 2)) + 4 * h + (e & 3)];
     }
     out[i] = v;
   }
@@ -321,11 +328,11 @@ extern "C" int bd_ffn_pack_weights(const void* w1, const void* w2, void* out, in
   return bd_check_launch("bd_ffn_pack_weights");
 }
 
-template <int NT, int DBG = 0>
+template <int NT>
 static int launch_ffn(const FfnArgs& a, hipStream_t stream) {
   const size_t lds = 6 * (size_t)NT * 1024 + ((size_t)a.F + 32) * 4;
-  hipFuncSetAttribute((const void*)ffn_fused_kernel<NT, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((ffn_fused_kernel<NT, DBG>), dim3((a.M + 127) / 128), dim3(256), lds, stream, a);
+  hipFuncSetAttribute((const void*)ffn_fused_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((ffn_fused_kernel<NT>), dim3((a.M + 127) / 128), dim3(256), lds, stream, a);
   return bd_check_launch("bd_ffn_fused");
 }
 
@@ -335,27 +342,23 @@ extern "C" int bd_ffn_fused(const float* x, float* out, const void* wpack, const
   BD_REQUIRE(x && out && wpack && b1 && b2, "bd_ffn_fused: null pointer");
   BD_REQUIRE(M > 0, "bd_ffn_fused: M=%d", M);
   BD_REQUIRE(bd_ffn_fused_supported(d, F), "bd_ffn_fused: unsupported d=%d F=%d", d, F);
-  FfnArgs a{x, out, (const unsigned char*)wpack, b1, b2, M, F, eps};
+  FfnArgs a{x, out, (const unsigned char*)wpack, b1, b2, M, F, eps, 0, 0};
+  {
+    static int ncu = 0;
+    if (!ncu) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+      else ncu = 256;
+    }
+    a.stagger_units = 3;
+    // only worth it when every CU runs several workgroups in a row
+    a.stagger_blocks = ((M + 127) / 128 >= 4 * ncu) ? ncu : 0;
+  }
   void* tok = bd_prof_on() ? bd_prof_begin(stream) : nullptr;
   int rc;
   switch (d) {
-    case 384: {
-      const char* e = getenv("BD_FFN_DBG");
-      const int dbg = e ? atoi(e) : 0;
-      switch (dbg) {
-        case 1: rc = launch_ffn<24, 1>(a, stream); break;
-        case 3: rc = launch_ffn<24, 3>(a, stream); break;
-        case 4: rc = launch_ffn<24, 4>(a, stream); break;
-        case 8: rc = launch_ffn<24, 8>(a, stream); break;
-        case 16: rc = launch_ffn<24, 16>(a, stream); break;
-        case 24: rc = launch_ffn<24, 24>(a, stream); break;
-        case 28: rc = launch_ffn<24, 28>(a, stream); break;
-        case 31: rc = launch_ffn<24, 31>(a, stream); break;
-        case 32: rc = launch_ffn<24, 32>(a, stream); break;
-        default: rc = launch_ffn<24>(a, stream); break;
-      }
-      break;
-    }
+    case 384: rc = launch_ffn<24>(a, stream); break;
     case 256: rc = launch_ffn<16>(a, stream); break;
     default: rc = launch_ffn<8>(a, stream); break;
   }

@@ -17,7 +17,6 @@
 // which lets a K-deep layer stream K once).
 #include "bd_common.h"
 #include "bd_prof.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -34,7 +33,6 @@ struct PanelArgs {
   int M, N, K, ldc;
   int nkc, ngroups;          // K chunks, groups of NACC output tiles
   float eps;
-  int dbg;                   // timing-only ablation bits (0 in production): 1 no prefetch loads, 2 no LDS writes, 4 no MFMA, 8 no barrier
 };
 
 __device__ __forceinline__ int pswz_w(int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); }
@@ -178,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void gemm_panel_kernel(PanelArgs p) {
           const int pos = nb * KS64 + k64;          // compile-time after unrolling
           const int set = pos % D;                  // register set and LDS buffer of stage s
           // 1. prefetch stage s + D into the register set of stage s (already written to LDS)
-          if (s + D < S && !(p.dbg & 1)) {
+          if (s + D < S) {
             int pg = grp, pk = kc, ppos = pos + D;
             if (ppos >= NACC * KS64) {
               ppos -= NACC * KS64;
@@ -201,16 +199,15 @@ __global__ __launch_bounds__(512, 2) void gemm_panel_kernel(PanelArgs p) {
             for (int t = 0; t < 4; ++t)
 #pragma unroll
               for (int mt = 0; mt < 2; ++mt)
-                if (!(p.dbg & 4)) acc[nb][t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[t], afr[mt][2 * k64 + kk], acc[nb][t][mt], 0, 0, 0);
-            if (p.dbg & 4) { asm volatile("" :: "v"(fw[0]), "v"(fw[1]), "v"(fw[2]), "v"(fw[3])); }
+                acc[nb][t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[t], afr[mt][2 * k64 + kk], acc[nb][t][mt], 0, 0, 0);
           }
           // 3. stage s + 1 (in registers since D - 1 iterations) goes to the next LDS buffer
-          if (s + 1 < S && !(p.dbg & 2)) {
+          if (s + 1 < S) {
             unsigned char* Wn = smem + ((set + 1) % D) * W_TILE;
 #pragma unroll
             for (int i = 0; i < 2; ++i) *(u32x4*)(Wn + soff[i]) = rw[(set + 1) % D][i];
           }
-          if (!(p.dbg & 8)) __syncthreads();
+          __syncthreads();
         }
       }
     }
@@ -323,7 +320,6 @@ extern "C" int bd_gemm_panel(const void* A, const void* W, const float* bias, vo
   PanelArgs a;
   a.A = A; a.W = (const unsigned short*)W; a.bias = bias; a.out = out; a.resid = resid;
   a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.eps = eps;
-  { const char* e = getenv("BD_PANEL_DBG"); a.dbg = e ? atoi(e) : 0; }
   const int ntiles = N / PBN;
   hipStream_t s = (hipStream_t)stream;
   const bool ln = layernorm_a != 0;

@@ -1,0 +1,23 @@
+import sys, math, os, torch
+sys.path.insert(0, 'discrete-diffusion-model-for-inverse-polymer-design_amd'); sys.path.insert(0, '.')
+from bidiff import _lib
+dev = torch.device('cuda:0'); lib = _lib.lib(); s = _lib.stream_handle()
+M, d, F = 4096 * 128, 384, 1536
+x = torch.randn(M, d, device=dev)
+w1 = (torch.randn(F, d, device=dev) / math.sqrt(d)).bfloat16(); w2 = (torch.randn(d, F, device=dev) / math.sqrt(F)).bfloat16()
+b1 = torch.randn(F, device=dev) * 0.1; b2 = torch.randn(d, device=dev) * 0.1
+pack = torch.empty(lib.bd_ffn_pack_bytes(d, F), dtype=torch.uint8, device=dev)
+lib.bd_ffn_pack_weights(_lib.ptr(w1), _lib.ptr(w2), _lib.ptr(pack), d, F, s)
+out = torch.empty_like(x)
+def t(iters=10):
+    call = lambda: lib.bd_ffn_fused(_lib.ptr(x), _lib.ptr(out), _lib.ptr(pack), _lib.ptr(b1), _lib.ptr(b2), M, d, F, 1e-5, s)
+    for _ in range(2): call()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): call()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+for st in (0, 1, 2, 3, 4, 6, 8):
+    os.environ["BD_FFN_STAGGER"] = str(st)
+    print(f"stagger {st}: {t():.1f} us", flush=True)
