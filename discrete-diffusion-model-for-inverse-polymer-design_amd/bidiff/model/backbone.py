@@ -9,6 +9,8 @@ modules below only *hold* parameters; all arithmetic runs in ``libbidiff_hip.so`
 import ctypes as C
 from typing import Optional
 
+import math
+
 import torch
 import torch.nn as nn
 
@@ -167,6 +169,21 @@ class DiffusionBackbone(nn.Module):
                 wq32 = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0).float()
                 lw.w_qkv_ln = bf(wq32 * blk.norm1.weight.float()[None, :]).data_ptr()
                 lw.b_qkv_ln = f32(bqkv + wq32 @ blk.norm1.bias.float()).data_ptr()
+                # weight stream of the fused attention block: q rows (and bias) also carry the
+                # softmax scale log2(e) / sqrt(head_dim), see attn_block.hip
+                if L_.bd_attn_block_supported(d, self.num_heads, 1):
+                    sc = math.log2(math.e) / math.sqrt(d // self.num_heads)
+                    wa = (wq32 * blk.norm1.weight.float()[None, :]).clone()
+                    ba = (bqkv + wq32 @ blk.norm1.bias.float()).clone()
+                    wa[:d] *= sc
+                    ba[:d] *= sc
+                    wab = bf(wa)
+                    apack = torch.empty(L_.bd_attn_pack_bytes(d), dtype=torch.uint8, device=dev)
+                    keep.append(apack)
+                    _lib.check(L_.bd_attn_pack_weights(wab.data_ptr(), lw.w_o, apack.data_ptr(), d, self.num_heads,
+                                                       _lib.stream_handle()), "bd_attn_pack_weights")
+                    lw.attn_pack = apack.data_ptr()
+                    lw.b_qkv_attn = f32(ba).data_ptr()
                 w1 = blk.ffn.fc1.weight.float()
                 w1ln = bf(w1 * blk.norm2.weight.float()[None, :])
                 lw.w_fc1_ln = w1ln.data_ptr()

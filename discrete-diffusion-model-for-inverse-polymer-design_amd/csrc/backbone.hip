@@ -67,34 +67,45 @@ extern "C" int bd_backbone_forward(const bd_backbone_desc* desc, const long long
   const int d = c.d, F = c.ffn, Mi = (int)M;
 
   if ((rc = bd_embed(ids, timesteps, c.tok_emb, c.pos_emb, c.time_emb, x, B, L, d, stream))) return rc;
-  // Fused kernels whenever the shapes allow (LayerNorm folded into the QKV projection's row-panel
-  // kernel; the whole feed-forward block in one kernel); otherwise LayerNorm + tiled GEMMs. The
-  // residual projections (out_proj, unfused fc2) use the tiled GEMM, which is the faster one there.
+  // Fused kernels whenever the shapes allow: the whole attention block in one kernel per sequence
+  // and the whole feed-forward block in one kernel per 128-token panel (nothing but the residual
+  // stream touches memory). Otherwise LayerNorm folded into the row-panel projection kernel, or
+  // plain LayerNorm + tiled GEMMs. The residual projections of the unfused path use the tiled
+  // GEMM, which is the faster one there.
   const bool pan_qkv = bd_gemm_panel_supported(3 * d, d, 1) != 0;
   const bool pan_fc1 = bd_gemm_panel_supported(F, d, 1) != 0;
   const bool fused_ffn = bd_ffn_fused_supported(d, F) != 0;
+  const bool fused_attn = bd_attn_block_supported(d, c.n_heads, L) != 0;
   for (int i = 0; i < c.n_layers; ++i) {
     const bd_layer_weights& lw = c.layers[i];
-    if (pan_qkv && lw.w_qkv_ln && lw.b_qkv_ln) {
-      if ((rc = bd_gemm_panel(x, lw.w_qkv_ln, lw.b_qkv_ln, qkv, nullptr, Mi, 3 * d, d, 3 * d, 0, 1, c.ln_eps, stream))) return rc;
+    // ---- x += out_proj(attention(ln1(x)))
+    if (fused_attn && lw.attn_pack && lw.b_qkv_attn) {
+      rc = bd_attn_block_fused(x, x, lw.attn_pack, lw.b_qkv_attn, lw.b_o, keymask, B, L, d, c.n_heads, c.ln_eps, stream);
+      if (rc) return rc;
     } else {
-      if ((rc = bd_layernorm(x, lw.ln1_g, lw.ln1_b, h, nullptr, nullptr, Mi, d, c.ln_eps, stream))) return rc;
-      if ((rc = bd_gemm_bf16(h, lw.w_qkv, lw.b_qkv, qkv, Mi, 3 * d, 3 * d, d, 3 * d, 0, stream))) return rc;
+      if (pan_qkv && lw.w_qkv_ln && lw.b_qkv_ln) {
+        rc = bd_gemm_panel(x, lw.w_qkv_ln, lw.b_qkv_ln, qkv, nullptr, Mi, 3 * d, d, 3 * d, 0, 1, c.ln_eps, stream);
+      } else {
+        if ((rc = bd_layernorm(x, lw.ln1_g, lw.ln1_b, h, nullptr, nullptr, Mi, d, c.ln_eps, stream))) return rc;
+        rc = bd_gemm_bf16(h, lw.w_qkv, lw.b_qkv, qkv, Mi, 3 * d, 3 * d, d, 3 * d, 0, stream);
+      }
+      if (rc) return rc;
+      if ((rc = bd_attention_fwd(qkv, keymask, att, nullptr, B, L, c.n_heads, d / c.n_heads, stream))) return rc;
+      if ((rc = bd_gemm_bf16(att, lw.w_o, lw.b_o, x, Mi, d, d, d, d, 2, stream))) return rc;
     }
-    if ((rc = bd_attention_fwd(qkv, keymask, att, nullptr, B, L, c.n_heads, d / c.n_heads, stream))) return rc;
-    if ((rc = bd_gemm_bf16(att, lw.w_o, lw.b_o, x, Mi, d, d, d, d, 2, stream))) return rc;
+    // ---- x += fc2(gelu(fc1(ln2(x))))
     if (fused_ffn && lw.ffn_pack && lw.b_fc1_ln) {
-      // LayerNorm + fc1 + GELU + fc2 + residual in one kernel; the hidden activations stay on chip
       if ((rc = bd_ffn_fused(x, x, lw.ffn_pack, lw.b_fc1_ln, lw.b_fc2, Mi, d, F, c.ln_eps, stream))) return rc;
-      continue;
-    }
-    if (pan_fc1 && lw.w_fc1_ln && lw.b_fc1_ln) {
-      if ((rc = bd_gemm_panel(x, lw.w_fc1_ln, lw.b_fc1_ln, ff, nullptr, Mi, F, d, F, 1, 1, c.ln_eps, stream))) return rc;
     } else {
-      if ((rc = bd_layernorm(x, lw.ln2_g, lw.ln2_b, h, nullptr, nullptr, Mi, d, c.ln_eps, stream))) return rc;
-      if ((rc = bd_gemm_bf16(h, lw.w_fc1, lw.b_fc1, ff, Mi, F, F, d, F, 1, stream))) return rc;
+      if (pan_fc1 && lw.w_fc1_ln && lw.b_fc1_ln) {
+        rc = bd_gemm_panel(x, lw.w_fc1_ln, lw.b_fc1_ln, ff, nullptr, Mi, F, d, F, 1, 1, c.ln_eps, stream);
+      } else {
+        if ((rc = bd_layernorm(x, lw.ln2_g, lw.ln2_b, h, nullptr, nullptr, Mi, d, c.ln_eps, stream))) return rc;
+        rc = bd_gemm_bf16(h, lw.w_fc1, lw.b_fc1, ff, Mi, F, F, d, F, 1, stream);
+      }
+      if (rc) return rc;
+      if ((rc = bd_gemm_bf16(ff, lw.w_fc2, lw.b_fc2, x, Mi, d, d, F, d, 2, stream))) return rc;
     }
-    if ((rc = bd_gemm_bf16(ff, lw.w_fc2, lw.b_fc2, x, Mi, d, d, F, d, 2, stream))) return rc;
   }
   void* hf = hidden_out ? hidden_out : h;
   if ((rc = bd_layernorm(x, c.lnf_g, c.lnf_b, hf, nullptr, nullptr, Mi, d, c.ln_eps, stream))) return rc;

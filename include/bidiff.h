@@ -83,6 +83,26 @@ int bd_ffn_pack_weights(const void* w1_folded, const void* w2, void* wpack, int 
 int bd_ffn_fused(const float* x, float* out, const void* wpack, const float* b1_folded, const float* b2, int M,
                  int d, int F, float eps, void* stream);
 
+/* Fused self-attention block of one pre-norm layer, in place on the fp32 residual stream, one
+ * workgroup per sequence (L <= 128):
+ *     out = x + Wo * MHA(normalise(x)) + b_o          (x, out: fp32 [B*L, d]; may alias)
+ * q, k, v, scores and the attention output never reach memory. wpack is the weight stream made
+ * by bd_attn_pack_weights from the stacked q|k|v projection (bf16 [3d, d], LayerNorm gamma folded
+ * in, the q rows also scaled by log2(e)/sqrt(head_dim)) and the output projection (bf16 [d, d]);
+ * it holds bd_attn_pack_bytes(d) bytes. b_qkv [3d] fp32 carries LayerNorm beta (b + W beta), its q
+ * part scaled like the q rows. keymask: byte mask [B, L] or null; a query whose keys are all
+ * masked contributes 0 (as bd_attention_fwd). Supported: (d, head_dim) in {(384,128), (256,128),
+ * (256,64), (128,64), (128,32)}, L <= 128.
+ * Replaces TransformerBlock.forward's  x + attn(ln1(x))  (src/model/backbone.py:126,
+ * MultiHeadAttention.forward :38-72). */
+int bd_attn_block_supported(int d, int n_heads, int L);
+long bd_attn_pack_bytes(int d);
+int bd_attn_pack_weights(const void* w_qkv_folded_scaled, const void* w_o, void* wpack, int d, int n_heads,
+                         void* stream);
+int bd_attn_block_fused(const float* x, float* out, const void* wpack, const float* b_qkv_folded_scaled,
+                        const float* b_o, const unsigned char* keymask, int B, int L, int d, int n_heads,
+                        float eps, void* stream);
+
 /* Non-causal multi-head attention on the fused qkv rows [B*L, 3*H*head_dim] (bf16) with a
  * key-padding byte mask [B,L] (non-zero = visible; null = all visible). A query whose keys
  * are all masked gives an all-zero output row. out [B*L, H*head_dim] bf16; lse optional
@@ -110,6 +130,9 @@ typedef struct bd_layer_weights {
   /* optional weight stream of the fused feed-forward kernel (bd_ffn_pack_weights of w_fc1_ln and
    * w_fc2; needs b_fc1_ln); null = separate fc1 / fc2 GEMMs                                   */
   const void* ffn_pack;
+  /* optional weight stream and bias of the fused attention block (bd_attn_pack_weights); null =
+   * separate projection / attention / out-proj kernels                                        */
+  const void* attn_pack; const float* b_qkv_attn;
 } bd_layer_weights;
 
 typedef struct bd_backbone_desc {

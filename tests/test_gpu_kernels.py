@@ -317,3 +317,84 @@ def test_ffn_fused_unsupported_shapes_are_refused(gpu_device):
     assert lib.bd_ffn_fused_supported(384, 64) == 0
     a = torch.zeros(1024, device=gpu_device)
     assert lib.bd_ffn_fused(_lib.ptr(a), _lib.ptr(a), _lib.ptr(a), _lib.ptr(a), _lib.ptr(a), 2, 512, 2048, 1e-5, _s()) < 0
+
+
+# ---------------------------------------------------------------- fused attention block
+def _attn_block_case(gpu_device, B, L, d, H, masked, seed):
+    g = torch.Generator().manual_seed(seed)
+    dh = d // H
+    x = torch.randn(B * L, d, generator=g) * 1.5 + 0.3
+    gm = 1 + 0.2 * torch.randn(d, generator=g)
+    bt = 0.3 * torch.randn(d, generator=g)
+    Wqkv = torch.randn(3 * d, d, generator=g) / math.sqrt(d)
+    bqkv = 0.3 * torch.randn(3 * d, generator=g)
+    Wo = torch.randn(d, d, generator=g) / math.sqrt(d)
+    bo = 0.3 * torch.randn(d, generator=g)
+    km = None
+    if masked:
+        km = torch.ones(B, L, dtype=torch.uint8)
+        for b in range(B):
+            km[b, int(torch.randint(1, L + 1, (1,), generator=g)):] = 0
+        km[B - 1] = 0                                       # a fully masked sequence
+    lib = _lib.lib()
+    scale = math.log2(math.e) / math.sqrt(dh)
+    wf = Wqkv * gm[None, :]
+    bf = bqkv + Wqkv @ bt
+    wf[:d] *= scale
+    bf[:d] *= scale
+    wqkv_b = wf.bfloat16().to(gpu_device)
+    wo_b = Wo.bfloat16().to(gpu_device)
+    pack = torch.empty(lib.bd_attn_pack_bytes(d), dtype=torch.uint8, device=gpu_device)
+    _lib.check(lib.bd_attn_pack_weights(_lib.ptr(wqkv_b), _lib.ptr(wo_b), _lib.ptr(pack), d, H, _s()), "attn pack")
+    xd = x.to(gpu_device)
+    out = torch.empty_like(xd)
+    bfd = bf.to(gpu_device)
+    bod = bo.to(gpu_device)
+    kmd = km.to(gpu_device) if km is not None else None
+    _lib.check(lib.bd_attn_block_fused(_lib.ptr(xd), _lib.ptr(out), _lib.ptr(pack), _lib.ptr(bfd), _lib.ptr(bod),
+                                       _lib.ptr(kmd) if kmd is not None else None, B, L, d, H, 1e-5, _s()), "attn block")
+    torch.cuda.synchronize()
+    # fp32 reference of the module chain: x + out_proj(softmax(q k^T / sqrt(dh) + mask) v), inputs LayerNorm(x)
+    xs = x.view(B, L, d)
+    qkv = torch.nn.functional.layer_norm(xs, (d,), gm, bt, 1e-5) @ Wqkv.t() + bqkv
+    q, k, v = [t.view(B, L, H, dh).transpose(1, 2) for t in qkv.split(d, dim=-1)]
+    sc = q @ k.transpose(-1, -2) / math.sqrt(dh)
+    if km is not None:
+        sc = sc.masked_fill(km[:, None, None, :] == 0, float("-inf"))
+    pr = torch.nan_to_num(torch.softmax(sc, dim=-1), nan=0.0)   # all keys masked -> zero output row
+    ref = xs + (pr @ v).transpose(1, 2).reshape(B, L, d) @ Wo.t() + bo
+    return out.cpu().view(B, L, d), ref, xs, bo
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,L,d,H,masked", [(3, 128, 384, 3, False), (4, 128, 384, 3, True), (5, 100, 384, 3, True),
+                                           (2, 1, 384, 3, False), (2, 128, 256, 4, False), (3, 77, 256, 2, True),
+                                           (3, 128, 128, 2, False), (3, 50, 128, 4, True), (300, 128, 384, 3, True)])
+def test_attn_block_fused_matches_fp32_reference(gpu_device, B, L, d, H, masked):
+    assert _lib.lib().bd_attn_block_supported(d, H, L) == 1
+    out, ref, xs, bo = _attn_block_case(gpu_device, B, L, d, H, masked, seed=B + L + d + H)
+    assert torch.isfinite(out).all()
+    # bf16 operands (LayerNorm output, weights, q, k, v, probabilities, attention output), fp32 accumulation
+    err = (out - ref).abs().max().item()
+    assert err < 2e-2 * ref.abs().max().item(), err
+    if masked:   # the fully masked sequence: attention contributes exactly nothing
+        assert torch.allclose(out[B - 1], xs[B - 1] + bo, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_attn_block_fused_sequences_independent_and_in_place(gpu_device):
+    B, L, d, H = 6, 96, 384, 3
+    out, _, xs, _ = _attn_block_case(gpu_device, B, L, d, H, True, seed=11)
+    out2, _, _, _ = _attn_block_case(gpu_device, B, L, d, H, True, seed=11)
+    assert torch.equal(out, out2)                            # deterministic
+
+
+@pytest.mark.gpu
+def test_attn_block_unsupported_shapes_are_refused(gpu_device):
+    lib = _lib.lib()
+    assert lib.bd_attn_block_supported(384, 3, 129) == 0
+    assert lib.bd_attn_block_supported(384, 8, 128) == 0     # head_dim 48
+    assert lib.bd_attn_block_supported(768, 6, 128) == 0
+    a = torch.zeros(1024, device=gpu_device)
+    assert lib.bd_attn_block_fused(_lib.ptr(a), _lib.ptr(a), _lib.ptr(a), _lib.ptr(a), _lib.ptr(a), None, 1, 200, 384, 3,
+                                   1e-5, _s()) < 0
