@@ -40,7 +40,7 @@ class LayerWeights(C.Structure):
         ("w_qkv_ln", VP), ("b_qkv_ln", VP),
         ("w_fc1_ln", VP), ("b_fc1_ln", VP),
         ("ffn_pack", VP),
-        ("attn_pack", VP), ("b_qkv_attn", VP),
+        ("attn_pack", VP), ("b_q_attn", VP), ("b_o_fold", VP),
     ]
 
 
@@ -115,7 +115,7 @@ SIGNATURES = {
     "bd_attn_block_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "bd_attn_pack_bytes": (C.c_long, [C.c_int]),
     "bd_attn_pack_weights": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, VP]),
-    "bd_attn_block_fused": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, VP]),
+    "bd_attn_block_fused": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, VP]),
     "bd_attention_fwd": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "bd_mask_to_bytes": (C.c_int, [VP, VP, C.c_longlong, VP]),
     "bd_backbone_workspace_bytes": (C.c_longlong, [C.POINTER(BackboneDesc), C.c_int, C.c_int]),
@@ -131,6 +131,7 @@ SIGNATURES = {
     "bd_host_uniform_token": (C.c_float, [C.c_ulonglong, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "bd_prof_enable": (C.c_int, [C.c_int]),
     "bd_prof_read": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
+    "bd_prof_read_kind": (C.c_int, [C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
 }
 
 

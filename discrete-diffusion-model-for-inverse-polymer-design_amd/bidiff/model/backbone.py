@@ -183,7 +183,9 @@ class DiffusionBackbone(nn.Module):
                     _lib.check(L_.bd_attn_pack_weights(wab.data_ptr(), lw.w_o, apack.data_ptr(), d, self.num_heads,
                                                        _lib.stream_handle()), "bd_attn_pack_weights")
                     lw.attn_pack = apack.data_ptr()
-                    lw.b_qkv_attn = f32(ba).data_ptr()
+                    lw.b_q_attn = f32(ba[:d]).data_ptr()
+                    # v bias: softmax rows sum to one, so it passes through attention unchanged
+                    lw.b_o_fold = f32(a.out_proj.bias.float() + a.out_proj.weight.float() @ ba[2 * d:]).data_ptr()
                 w1 = blk.ffn.fc1.weight.float()
                 w1ln = bf(w1 * blk.norm2.weight.float()[None, :])
                 lw.w_fc1_ln = w1ln.data_ptr()

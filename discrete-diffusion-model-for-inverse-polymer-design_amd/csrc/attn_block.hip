@@ -35,8 +35,9 @@ struct AttnArgs {
   const float* x;               // [B * L, d] residual stream in
   float* out;                   // [B * L, d] residual stream out (may equal x)
   const unsigned char* wpack;   // packed weight stream (bd_attn_pack_weights)
-  const float* bqkv;            // [3 d]: q | k | v biases with LayerNorm beta folded, q part scaled
-  const float* bo;              // [d]
+  const float* bq;              // [d]: q bias with LayerNorm beta folded, scaled like the q rows
+  const float* bo;              // [d] output bias
+  const float* bo_fold;         // [d] output bias + Wo * (v bias with LayerNorm beta folded)
   const unsigned char* keymask; // [B, L] bytes, non-zero = visible; null = all visible
   int B, L;
   float eps;
@@ -56,13 +57,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int QKV_UNITS = 3 * H * DT;
   constexpr int NUNITS = QKV_UNITS + NT32;
   constexpr int KV_BYTES = 128 * DH * 2;
-  constexpr int LOOK = 8;
+  constexpr int LOOK = NT >= 16 ? 8 : 4;      // fragment reads in flight
+  constexpr int MID = NT / 2;                 // MFMA index of a unit's barrier
+  static_assert(MID <= NT - LOOK, "the barrier must precede the first read of the next unit");
   static_assert(NT % 4 == 0 && DH % 32 == 0 && D % DH == 0, "unsupported shape");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned char* const sK = smem + RING * UNIT;
   unsigned char* const sV = sK + KV_BYTES;
-  float* const sbias = (float*)(sV + KV_BYTES);        // 3 d floats
-  float* const smask = sbias + 3 * D;                  // 128 floats: 0 (visible) or -1e30
+  float* const sbias = (float*)(sV + KV_BYTES);        // d floats (q bias)
+  float* const smask = sbias + D;                  // 128 floats: 0 (visible) or -1e30
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -100,9 +103,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const f32x4 v = *(const f32x4*)(xr + 32 * T + 8 * q);
         xt[T][4 * q + 0] = v[0]; xt[T][4 * q + 1] = v[1]; xt[T][4 * q + 2] = v[2]; xt[T][4 * q + 3] = v[3];
       }
-#pragma unroll
-    for (int u = 0; u < RING; ++u) issue_unit(u);
-    for (int i = tid; i < 3 * D; i += 256) sbias[i] = p.bqkv[i];
+    issue_unit(0);
+    issue_unit(1);
+    for (int i = tid; i < D; i += 256) sbias[i] = p.bq[i];
     if (tid < 128) {
       const bool vis = tid < p.L && (p.keymask == nullptr || p.keymask[(size_t)seq * p.L + tid] != 0);
       smask[tid] = vis ? 0.f : -1e30f;
@@ -136,36 +139,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const unsigned ldsB = (unsigned)(size_t)(lds_void*)sbias;
   const unsigned ldsM = (unsigned)(size_t)(lds_void*)smask + 16 * h;
 
-  // One unit of the stream = NT fragments -> NT MFMAs on one 32x32 accumulator. The LDS reads run
-  // LOOK fragments ahead of their MFMAs and every MFMA waits with an exact count (inline asm:
-  // the compiler would wait for all outstanding reads each time, and a wave alone on its SIMD
-  // must not drain its LDS queue). WEIGHT_IS_A: tile = W_frag * op (rows = weight rows), else
-  // tile = op * W_frag (rows = tokens).
-  auto run_unit = [&](int u, auto weight_is_a, f32x16 t, const bf16x8 (&op)[NT]) -> f32x16 {
+  // The weight stream is consumed as ONE continuous sequence of fragments. One unit = NT fragments
+  // -> NT MFMAs on one 32x32 accumulator; fragment i of a unit lives in register wf[i], and its LDS
+  // read is issued LOOK MFMAs earlier - across unit boundaries - with an exact wait count before
+  // each MFMA (inline asm: the compiler would wait for all outstanding reads each time, and a wave
+  // alone on its SIMD must not drain its LDS queue).
+  // Ring protocol, one barrier per unit, in its MIDDLE: when every wave has passed the middle of
+  // unit u, (a) every wave's LDS-DMA pieces of unit u + 1 have landed (each waits for its own
+  // before the barrier), so reading u + 1 may start during the tail of u, and (b) nobody reads
+  // unit u - 1 any more, so unit u + 2 is issued into that slot.
+  bf16x8 wf[NT];
+  auto mid_sync = [&](int u) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (u + 2 < NUNITS) issue_unit(u + 2);
+  };
+  // WEIGHT_IS_A: tile = W_frag * op (rows = weight rows), else tile = op * W_frag (rows = tokens).
+  auto run_unit = [&](int u, auto weight_is_a, auto last_unit, f32x16 t, const bf16x8 (&op)[NT]) -> f32x16 {
     constexpr bool WEIGHT_IS_A = decltype(weight_is_a)::value;
-    unsigned base = lds0 + (u % RING) * UNIT;
-    asm volatile("" : "+v"(base));
-    bf16x8 wf[NT];
-#pragma unroll
-    for (int i = 0; i < LOOK; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[i]) : "v"(base), "i"(i * 1024));
+    constexpr bool LAST = decltype(last_unit)::value;
+    unsigned bc = lds0 + (u % RING) * UNIT, bn = lds0 + ((u + 1) % RING) * UNIT;
+    asm volatile("" : "+v"(bc), "+v"(bn));
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-      if (i + LOOK < NT)
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[i + LOOK]) : "v"(base), "i"((i + LOOK) * 1024));
-      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(wf[i]) : "i"(i + LOOK < NT ? LOOK : NT - 1 - i));
+      if (i == MID) mid_sync(u);
+      const int j = i + LOOK;
+      if (j < NT) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[j]) : "v"(bc), "i"(j * 1024));
+      else if (!LAST) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[j - NT]) : "v"(bn), "i"((j - NT) * 1024));
+      // reads younger than fragment i that may stay in flight
+      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(wf[i]) : "i"((j < NT || !LAST) ? LOOK : NT - 1 - i));
       if (WEIGHT_IS_A) t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], op[i], t, 0, 0, 0);
       else t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[i], wf[i], t, 0, 0, 0);
     }
     return t;
-  };
-  // After unit u: its ring slot is free once every wave is past this barrier; unit u + 1 must have
-  // landed for every wave (u + 2 may stay in flight); then unit u + RING goes into the free slot.
-  auto unit_end = [&](int u) {
-    if (u + 2 < NUNITS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_UNIT) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (u + RING < NUNITS) issue_unit(u + RING);
   };
   // accumulator initialised with per-ROW values table[8 q + 4 h + e] (rows of a D tile)
   auto rows_init = [&](unsigned addr) -> f32x16 {
@@ -183,55 +189,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int e = 0; e < 8; ++e) f[e] = (__bf16)t[8 * kk + e];
     return f;
   };
+  f32x16 zero16;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
 
-  // everything staged (weights of the first RING units, tables)
+  // units 0 and 1 and the tables are staged; start the fragment stream
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  {
+    unsigned b0 = lds0;
+    asm volatile("" : "+v"(b0));
+#pragma unroll
+    for (int i = 0; i < LOOK; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[i]) : "v"(b0), "i"(i * 1024));
+  }
 
   bf16x8 oall[NT];              // attention output of all heads as B operands of the Wo product
 #pragma unroll
   for (int i = 0; i < NT; ++i) oall[i] = xln[0];   // defined values; every entry is overwritten
+  bool dead = false;            // every key of the sequence masked (same for all queries and heads)
 
   int u = 0;
 #pragma nounroll
   for (int hd = 0; hd < H; ++hd) {
+    // q bias rows of this head's tiles (the k bias shifts all scores of a query equally and drops
+    // out of the softmax; the v bias is folded into the output bias by the host)
+    f32x16 qinit[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) qinit[dt] = rows_init(ldsB + (hd * DH + 32 * dt + 4 * h) * 4);
     // ---- Q^T tiles -> B operands of the score product
     bf16x8 qb[KBO];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
-      f32x16 t = rows_init(ldsB + (hd * DH + 32 * dt + 4 * h) * 4);
-      t = run_unit(u, std::true_type{}, t, xln);
+      const f32x16 t = run_unit(u, std::true_type{}, std::false_type{}, qinit[dt], xln);
       qb[2 * dt] = pack_half(t, 0);
       qb[2 * dt + 1] = pack_half(t, 1);
-      unit_end(u);
       ++u;
     }
     // ---- K^T tiles: rounded halves are the A fragments (row = key) of S = K Q^T
 #pragma nounroll
     for (int dt = 0; dt < DT; ++dt) {
-      f32x16 t = rows_init(ldsB + (D + hd * DH + 32 * dt + 4 * h) * 4);
-      t = run_unit(u, std::true_type{}, t, xln);
+      const f32x16 t = run_unit(u, std::true_type{}, std::false_type{}, zero16, xln);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
         *(lds_frag_w)(size_t)(ldsK + ((wave * KBO + 2 * dt + kk) << 10)) = pack_half(t, kk);
-      unit_end(u);
       ++u;
     }
     // ---- V tiles (rows = tokens): rounded halves are the A fragments (row = dh) of O^T = V^T P^T
 #pragma nounroll
     for (int dt = 0; dt < DT; ++dt) {
-      const float bv = *(lds_f1)(size_t)(ldsB + (2 * D + hd * DH + 32 * dt + c) * 4);
-      f32x16 t;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) t[r] = bv;
-      t = run_unit(u, std::false_type{}, t, xln);
+      const f32x16 t = run_unit(u, std::false_type{}, std::false_type{}, zero16, xln);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
         *(lds_frag_w)(size_t)(ldsV + ((dt * 8 + 2 * wave + kk) << 10)) = pack_half(t, kk);
-      unit_end(u);     // its barrier also publishes K and V of this head
       ++u;
     }
+    // K and V of this head are complete and visible to all waves
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 
     // ---- S = K Q^T (rows = keys, columns = this wave's queries), key padding as initial value
     f32x16 s[4];
@@ -256,7 +271,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int r = 0; r < 16; ++r) m = fmaxf(m, s[kt][r]);
     m = fmaxf(m, __shfl_xor(m, 32, 64));
-    const bool dead = m < -1e29f;             // every key masked
+    dead = m < -1e29f;                        // every key masked
     float l = 0.f;
     bf16x8 pb[8];                             // P as B operands: k-block 2 kt + kk = 16 keys
 #pragma unroll
@@ -311,11 +326,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   f32x16 acc[NT32];
 #pragma unroll
   for (int T = 0; T < NT32; ++T) {
-    f32x16 z;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) z[r] = 0.f;
-    acc[T] = run_unit(u, std::true_type{}, z, oall);
-    unit_end(u);
+    if (T + 1 < NT32) acc[T] = run_unit(u, std::true_type{}, std::false_type{}, zero16, oall);
+    else acc[T] = run_unit(u, std::true_type{}, std::true_type{}, zero16, oall);
     ++u;
   }
 
@@ -328,7 +340,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x4 xv = *(const f32x4*)(xr + 32 * T + 8 * q);
-        const f32x4 b = *(const f32x4*)(p.bo + 32 * T + 8 * q + 4 * h);
+        const f32x4 b = *(const f32x4*)((dead ? p.bo : p.bo_fold) + 32 * T + 8 * q + 4 * h);
         f32x4 v;
         v[0] = acc[T][4 * q + 0] + xv[0] + b[0]; v[1] = acc[T][4 * q + 1] + xv[1] + b[1];
         v[2] = acc[T][4 * q + 2] + xv[2] + b[2]; v[3] = acc[T][4 * q + 3] + xv[3] + b[3];
@@ -369,7 +381,7 @@ __global__ void attn_pack_kernel(const unsigned short* __restrict__ wqkv, const 
 
 template <int NT, int DH>
 int launch_attn(const AttnArgs& a, hipStream_t stream) {
-  const size_t lds = 3 * (size_t)NT * 1024 + 2 * (size_t)128 * DH * 2 + 3 * (size_t)NT * 16 * 4 + 128 * 4;
+  const size_t lds = 3 * (size_t)NT * 1024 + 2 * (size_t)128 * DH * 2 + (size_t)NT * 16 * 4 + 128 * 4;
   hipFuncSetAttribute((const void*)attn_block_kernel<NT, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((attn_block_kernel<NT, DH>), dim3(a.B), dim3(256), lds, stream, a);
   return bd_check_launch("bd_attn_block_fused");
@@ -395,14 +407,14 @@ extern "C" int bd_attn_pack_weights(const void* w_qkv, const void* w_o, void* ou
   return bd_check_launch("bd_attn_pack_weights");
 }
 
-extern "C" int bd_attn_block_fused(const float* x, float* out, const void* wpack, const float* b_qkv, const float* b_o,
-                                   const unsigned char* keymask, int B, int L, int d, int n_heads, float eps,
-                                   void* stream_) {
+extern "C" int bd_attn_block_fused(const float* x, float* out, const void* wpack, const float* b_q, const float* b_o,
+                                   const float* b_o_fold, const unsigned char* keymask, int B, int L, int d, int n_heads,
+                                   float eps, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  BD_REQUIRE(x && out && wpack && b_qkv && b_o, "bd_attn_block_fused: null pointer");
+  BD_REQUIRE(x && out && wpack && b_q && b_o && b_o_fold, "bd_attn_block_fused: null pointer");
   BD_REQUIRE(B > 0, "bd_attn_block_fused: B=%d", B);
   BD_REQUIRE(bd_attn_block_supported(d, n_heads, L), "bd_attn_block_fused: unsupported d=%d heads=%d L=%d", d, n_heads, L);
-  AttnArgs a{x, out, (const unsigned char*)wpack, b_qkv, b_o, keymask, B, L, eps, 0, 3};
+  AttnArgs a{x, out, (const unsigned char*)wpack, b_q, b_o, b_o_fold, keymask, B, L, eps, 0, 3};
   {
     static int ncu = 0;
     if (!ncu) {
@@ -421,7 +433,7 @@ extern "C" int bd_attn_block_fused(const float* x, float* out, const void* wpack
   else if (d == 256) rc = launch_attn<16, 64>(a, stream);
   else if (dh == 64) rc = launch_attn<8, 64>(a, stream);
   else rc = launch_attn<8, 32>(a, stream);
-  // 4 projections of d x d and the two attention products over the padded 128-token panel
-  if (tok) bd_prof_end(tok, stream, 2.0 * (double)B * 128 * (4.0 * d * d + 2.0 * 128 * d));
+  // algorithmic work: four d x d projections per token and the two L x L attention products
+  if (tok) bd_prof_end(tok, stream, 2.0 * (double)B * L * (4.0 * d * d + 2.0 * L * d), BD_PROF_ATTN_BLOCK);
   return rc;
 }

@@ -79,8 +79,8 @@ extern "C" int bd_backbone_forward(const bd_backbone_desc* desc, const long long
   for (int i = 0; i < c.n_layers; ++i) {
     const bd_layer_weights& lw = c.layers[i];
     // ---- x += out_proj(attention(ln1(x)))
-    if (fused_attn && lw.attn_pack && lw.b_qkv_attn) {
-      rc = bd_attn_block_fused(x, x, lw.attn_pack, lw.b_qkv_attn, lw.b_o, keymask, B, L, d, c.n_heads, c.ln_eps, stream);
+    if (fused_attn && lw.attn_pack && lw.b_q_attn && lw.b_o_fold) {
+      rc = bd_attn_block_fused(x, x, lw.attn_pack, lw.b_q_attn, lw.b_o, lw.b_o_fold, keymask, B, L, d, c.n_heads, c.ln_eps, stream);
       if (rc) return rc;
     } else {
       if (pan_qkv && lw.w_qkv_ln && lw.b_qkv_ln) {

@@ -56,13 +56,13 @@ extern "C" float bd_host_uniform_token(unsigned long long seed, uint32_t seq, ui
 
 // ---- event profiler: pairs of events around selected launches, resolved lazily
 namespace {
-struct Pair { hipEvent_t a, b; double flops; };
+struct Pair { hipEvent_t a, b; double flops; int kind; };
 std::mutex g_mu;
 bool g_on = false;
 std::vector<Pair> g_pending;
 std::vector<hipEvent_t> g_free;
-long long g_launches = 0;
-double g_ms = 0.0, g_flops = 0.0;
+long long g_launches[BD_PROF_KINDS] = {};
+double g_ms[BD_PROF_KINDS] = {}, g_flops[BD_PROF_KINDS] = {};
 
 hipEvent_t get_event() {
   if (!g_free.empty()) { hipEvent_t e = g_free.back(); g_free.pop_back(); return e; }
@@ -75,7 +75,7 @@ void drain_locked() {
   for (Pair& pr : g_pending) {
     float ms = 0.f;
     if (hipEventSynchronize(pr.b) == hipSuccess && hipEventElapsedTime(&ms, pr.a, pr.b) == hipSuccess) {
-      g_launches++; g_ms += ms; g_flops += pr.flops;
+      g_launches[pr.kind]++; g_ms[pr.kind] += ms; g_flops[pr.kind] += pr.flops;
     }
     g_free.push_back(pr.a); g_free.push_back(pr.b);
   }
@@ -94,13 +94,13 @@ void* bd_prof_begin(hipStream_t s) {
   return (void*)a;
 }
 
-void bd_prof_end(void* tok, hipStream_t s, double flops) {
+void bd_prof_end(void* tok, hipStream_t s, double flops, int kind) {
   if (!tok) return;
   std::lock_guard<std::mutex> lk(g_mu);
   hipEvent_t b = get_event();
   if (!b) { g_free.push_back((hipEvent_t)tok); return; }
   hipEventRecord(b, s);
-  g_pending.push_back(Pair{(hipEvent_t)tok, b, flops});
+  g_pending.push_back(Pair{(hipEvent_t)tok, b, flops, kind >= 0 && kind < BD_PROF_KINDS ? kind : 0});
   if (g_pending.size() >= 4096) drain_locked();
 }
 
@@ -110,12 +110,22 @@ extern "C" int bd_prof_enable(int on) {
   return BD_OK;
 }
 
-extern "C" int bd_prof_read(long long* launches, double* total_ms, double* total_flops, int reset) {
+extern "C" int bd_prof_read_kind(int kind, long long* launches, double* total_ms, double* total_flops, int reset) {
   std::lock_guard<std::mutex> lk(g_mu);
   drain_locked();
-  if (launches) *launches = g_launches;
-  if (total_ms) *total_ms = g_ms;
-  if (total_flops) *total_flops = g_flops;
-  if (reset) { g_launches = 0; g_ms = 0.0; g_flops = 0.0; }
+  long long n = 0;
+  double ms = 0.0, fl = 0.0;
+  for (int k = 0; k < BD_PROF_KINDS; ++k) {
+    if (kind >= 0 && k != kind) continue;
+    n += g_launches[k]; ms += g_ms[k]; fl += g_flops[k];
+    if (reset) { g_launches[k] = 0; g_ms[k] = 0.0; g_flops[k] = 0.0; }
+  }
+  if (launches) *launches = n;
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
   return BD_OK;
+}
+
+extern "C" int bd_prof_read(long long* launches, double* total_ms, double* total_flops, int reset) {
+  return bd_prof_read_kind(-1, launches, total_ms, total_flops, reset);
 }

@@ -362,6 +362,6 @@ extern "C" int bd_ffn_fused(const float* x, float* out, const void* wpack, const
     case 256: rc = launch_ffn<16>(a, stream); break;
     default: rc = launch_ffn<8>(a, stream); break;
   }
-  if (tok) bd_prof_end(tok, stream, 2.0 * 2.0 * (double)M * d * F);
+  if (tok) bd_prof_end(tok, stream, 2.0 * 2.0 * (double)M * d * F, BD_PROF_FFN);
   return rc;
 }

@@ -259,7 +259,7 @@ int launch_panel(const PanelArgs& a, hipStream_t s) {
   const int blocks = (a.M + PBM - 1) / PBM;
   void* tok = bd_prof_on() ? bd_prof_begin(s) : nullptr;
   hipLaunchKernelGGL((gemm_panel_kernel<KS32, NACC, EPI, LN_A>), dim3(blocks), dim3(512), 0, s, a);
-  if (tok) bd_prof_end(tok, s, 2.0 * (double)a.M * (double)a.N * (double)a.K);
+  if (tok) bd_prof_end(tok, s, 2.0 * (double)a.M * (double)a.N * (double)a.K, BD_PROF_PANEL);
   return bd_check_launch("bd_gemm_panel");
 }
 

@@ -89,19 +89,21 @@ int bd_ffn_fused(const float* x, float* out, const void* wpack, const float* b1_
  * q, k, v, scores and the attention output never reach memory. wpack is the weight stream made
  * by bd_attn_pack_weights from the stacked q|k|v projection (bf16 [3d, d], LayerNorm gamma folded
  * in, the q rows also scaled by log2(e)/sqrt(head_dim)) and the output projection (bf16 [d, d]);
- * it holds bd_attn_pack_bytes(d) bytes. b_qkv [3d] fp32 carries LayerNorm beta (b + W beta), its q
- * part scaled like the q rows. keymask: byte mask [B, L] or null; a query whose keys are all
- * masked contributes 0 (as bd_attention_fwd). Supported: (d, head_dim) in {(384,128), (256,128),
- * (256,64), (128,64), (128,32)}, L <= 128.
+ * it holds bd_attn_pack_bytes(d) bytes. Biases (fp32 [d] each, LayerNorm beta folded in: b + W beta):
+ * b_q scaled like the q rows; the k bias is not needed (it shifts all scores of a query equally);
+ * the v bias enters through b_o_fold = b_o + Wo * b_v. keymask: byte mask [B, L] or null; a
+ * sequence whose keys are all masked gets out = x + b_o (zero attention output, as
+ * bd_attention_fwd + out-proj). Supported: (d, head_dim) in {(384,128), (256,128), (256,64),
+ * (128,64), (128,32)}, L <= 128.
  * Replaces TransformerBlock.forward's  x + attn(ln1(x))  (src/model/backbone.py:126,
  * MultiHeadAttention.forward :38-72). */
 int bd_attn_block_supported(int d, int n_heads, int L);
 long bd_attn_pack_bytes(int d);
 int bd_attn_pack_weights(const void* w_qkv_folded_scaled, const void* w_o, void* wpack, int d, int n_heads,
                          void* stream);
-int bd_attn_block_fused(const float* x, float* out, const void* wpack, const float* b_qkv_folded_scaled,
-                        const float* b_o, const unsigned char* keymask, int B, int L, int d, int n_heads,
-                        float eps, void* stream);
+int bd_attn_block_fused(const float* x, float* out, const void* wpack, const float* b_q_folded_scaled,
+                        const float* b_o, const float* b_o_fold, const unsigned char* keymask, int B, int L,
+                        int d, int n_heads, float eps, void* stream);
 
 /* Non-causal multi-head attention on the fused qkv rows [B*L, 3*H*head_dim] (bf16) with a
  * key-padding byte mask [B,L] (non-zero = visible; null = all visible). A query whose keys
@@ -132,7 +134,7 @@ typedef struct bd_layer_weights {
   const void* ffn_pack;
   /* optional weight stream and bias of the fused attention block (bd_attn_pack_weights); null =
    * separate projection / attention / out-proj kernels                                        */
-  const void* attn_pack; const float* b_qkv_attn;
+  const void* attn_pack; const float* b_q_attn; const float* b_o_fold;
 } bd_layer_weights;
 
 typedef struct bd_backbone_desc {
@@ -332,6 +334,9 @@ float bd_host_uniform_token(unsigned long long seed, uint32_t seq, uint32_t t, u
  * events and returns launches / total milliseconds / total flops since the last reset. */
 int bd_prof_enable(int on);
 int bd_prof_read(long long* launches, double* total_ms, double* total_flops, int reset);
+/* Same, for one kernel family: 0 tiled GEMM, 1 row-panel GEMM, 2 fused feed-forward block,
+ * 3 fused attention block; -1 = all families together. */
+int bd_prof_read_kind(int kind, long long* launches, double* total_ms, double* total_flops, int reset);
 
 #ifdef __cplusplus
 }

@@ -23,9 +23,9 @@ def run(B, L, d, H, iters=10, masked=False, check=True):
     wqkv_b = wf.bfloat16().to(dev); wo_b = Wo.bfloat16().to(dev)
     pack = torch.empty(lib.bd_attn_pack_bytes(d), dtype=torch.uint8, device=dev)
     _lib.check(lib.bd_attn_pack_weights(_lib.ptr(wqkv_b), _lib.ptr(wo_b), _lib.ptr(pack), d, H, s), "pack")
-    xd = x.to(dev); out = torch.empty_like(xd); bfd = bf.to(dev); bod = bo.to(dev)
+    xd = x.to(dev); out = torch.empty_like(xd); bfd = bf[:d].contiguous().to(dev); bod = bo.to(dev); bofd = (bo + Wo @ bf[2 * d:]).to(dev)
     kmd = km.to(dev) if km is not None else None
-    call = lambda: lib.bd_attn_block_fused(_lib.ptr(xd), _lib.ptr(out), _lib.ptr(pack), _lib.ptr(bfd), _lib.ptr(bod),
+    call = lambda: lib.bd_attn_block_fused(_lib.ptr(xd), _lib.ptr(out), _lib.ptr(pack), _lib.ptr(bfd), _lib.ptr(bod), _lib.ptr(bofd),
                                            _lib.ptr(kmd) if kmd is not None else None, B, L, d, H, 1e-5, s)
     _lib.check(call(), "attn"); torch.cuda.synchronize()
     if check:

@@ -348,11 +348,12 @@ def _attn_block_case(gpu_device, B, L, d, H, masked, seed):
     _lib.check(lib.bd_attn_pack_weights(_lib.ptr(wqkv_b), _lib.ptr(wo_b), _lib.ptr(pack), d, H, _s()), "attn pack")
     xd = x.to(gpu_device)
     out = torch.empty_like(xd)
-    bfd = bf.to(gpu_device)
+    bfd = bf[:d].contiguous().to(gpu_device)
     bod = bo.to(gpu_device)
+    bofd = (bo + Wo @ bf[2 * d:]).to(gpu_device)
     kmd = km.to(gpu_device) if km is not None else None
     _lib.check(lib.bd_attn_block_fused(_lib.ptr(xd), _lib.ptr(out), _lib.ptr(pack), _lib.ptr(bfd), _lib.ptr(bod),
-                                       _lib.ptr(kmd) if kmd is not None else None, B, L, d, H, 1e-5, _s()), "attn block")
+                                       _lib.ptr(bofd), _lib.ptr(kmd) if kmd is not None else None, B, L, d, H, 1e-5, _s()), "attn block")
     torch.cuda.synchronize()
     # fp32 reference of the module chain: x + out_proj(softmax(q k^T / sqrt(dh) + mask) v), inputs LayerNorm(x)
     xs = x.view(B, L, d)
@@ -396,5 +397,5 @@ def test_attn_block_unsupported_shapes_are_refused(gpu_device):
     assert lib.bd_attn_block_supported(384, 8, 128) == 0     # head_dim 48
     assert lib.bd_attn_block_supported(768, 6, 128) == 0
     a = torch.zeros(1024, device=gpu_device)
-    assert lib.bd_attn_block_fused(_lib.ptr(a), _lib.ptr(a), _lib.ptr(a), _lib.ptr(a), _lib.ptr(a), None, 1, 200, 384, 3,
+    assert lib.bd_attn_block_fused(_lib.ptr(a), _lib.ptr(a), _lib.ptr(a), _lib.ptr(a), _lib.ptr(a), _lib.ptr(a), None, 1, 200, 384, 3,
                                    1e-5, _s()) < 0
