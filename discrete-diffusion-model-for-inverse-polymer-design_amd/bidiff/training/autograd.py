@@ -39,12 +39,12 @@ def _ln_bwd(dy, x, stats, g, dres, dx, dg, db, M, d):
 
 
 def _wgrad(dY, X, dW, M, N, K):
-    _ck(_lib.lib().bd_gemm_wgrad_bf16(_lib.ptr(dY), dY.shape[-1], _lib.ptr(X), X.shape[-1], _lib.ptr(dW), M, N, K,
+    _ck(_lib.lib().bd_gemm_wgrad_bf16(_lib.ptr(dY), dY.stride(0), _lib.ptr(X), X.stride(0), _lib.ptr(dW), M, N, K,
                                       _s()), "bd_gemm_wgrad_bf16")
 
 
 def _colsum(dY, out, M, N):
-    _ck(_lib.lib().bd_colsum_bf16(_lib.ptr(dY), dY.shape[-1], _lib.ptr(out), M, N, _s()), "bd_colsum_bf16")
+    _ck(_lib.lib().bd_colsum_bf16(_lib.ptr(dY), dY.stride(0), _lib.ptr(out), M, N, _s()), "bd_colsum_bf16")
 
 
 def _to_bf16(x, out):
@@ -145,23 +145,39 @@ class _BackboneFn(torch.autograd.Function):
         d, F, V, H = model.hidden_size, model.ffn_hidden_size, model.vocab_size, model.num_heads
         dev = ids.device
         bf = torch.bfloat16
+        # Parameter gradients. The kernels ACCUMULATE (atomic adds), so when every parameter already
+        # has a dense fp32 .grad (FlatAdamW binds them to one flat buffer) they add straight into it
+        # and autograd gets None for the parameters: no per-parameter zero fill, no AccumulateGrad
+        # add. Otherwise fresh zero buffers are returned to autograd the usual way.
+        params = list(model.parameters())
+        direct = all(p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous()
+                     and p.grad.device == dev for p in params if p.requires_grad)
         grads = {}
+
+        def gbuf(p):
+            if direct and p.requires_grad:
+                return p.grad
+            g = torch.zeros_like(p, dtype=torch.float32)
+            grads[p] = g
+            return g
 
         def zeros(*shape):
             return torch.zeros(*shape, device=dev)
 
-        # vocabulary head
+        # vocabulary head (rows padded to a multiple of 128: own buffer, then one add / slice)
         dl = torch.zeros(M, tw.vpad, dtype=bf, device=dev)
         dl[:, :V] = dlogits.reshape(M, V)
         dwout = zeros(tw.vpad, d)
         _wgrad(dl, ctx.hf, dwout, M, tw.vpad, d)
-        grads[model.output_proj.weight] = dwout[:V]
+        if direct and model.output_proj.weight.requires_grad:
+            model.output_proj.weight.grad.add_(dwout[:V])
+        else:
+            grads[model.output_proj.weight] = dwout[:V]
         dh = torch.empty(M, d, dtype=bf, device=dev)
         _gemm(dl, tw.woutT, None, dh, M, d, d, tw.vpad, d, 0)
         dx = torch.empty(M, d, device=dev)
-        dg, db = zeros(d), zeros(d)
-        _ln_bwd(dh, ctx.x_last, ctx.stf, model.final_norm.weight, None, dx, dg, db, M, d)
-        grads[model.final_norm.weight], grads[model.final_norm.bias] = dg, db
+        _ln_bwd(dh, ctx.x_last, ctx.stf, model.final_norm.weight, None, dx, gbuf(model.final_norm.weight),
+                gbuf(model.final_norm.bias), M, d)
 
         dy = torch.empty(M, d, dtype=bf, device=dev)
         du = torch.empty(M, F, dtype=bf, device=dev)
@@ -169,51 +185,36 @@ class _BackboneFn(torch.autograd.Function):
         dqkv = torch.empty(M, 3 * d, dtype=bf, device=dev)
         delta = torch.empty(B, H, L, device=dev)
         for blk, w, s in zip(reversed(model.layers), reversed(tw.layers), reversed(ctx.saved)):
+            a = blk.attn
             # x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
             _to_bf16(dx, dy)
-            dw2, db2 = zeros(d, F), zeros(d)
-            _wgrad(dy, s["a"], dw2, M, d, F)
-            _colsum(dy, db2, M, d)
+            _wgrad(dy, s["a"], gbuf(blk.ffn.fc2.weight), M, d, F)
+            _colsum(dy, gbuf(blk.ffn.fc2.bias), M, d)
             _gemm(dy, w["w2T"], None, du, M, F, F, d, F, 4, aux_in=s["u"])
-            dw1, db1 = zeros(F, d), zeros(F)
-            _wgrad(du, s["h2"], dw1, M, F, d)
-            _colsum(du, db1, M, F)
+            _wgrad(du, s["h2"], gbuf(blk.ffn.fc1.weight), M, F, d)
+            _colsum(du, gbuf(blk.ffn.fc1.bias), M, F)
             _gemm(du, w["w1T"], None, dh, M, d, d, F, d, 0)
-            dg2, dbt2 = zeros(d), zeros(d)
-            _ln_bwd(dh, s["x_mid"], s["st2"], blk.norm2.weight, dx, dx, dg2, dbt2, M, d)
+            _ln_bwd(dh, s["x_mid"], s["st2"], blk.norm2.weight, dx, dx, gbuf(blk.norm2.weight), gbuf(blk.norm2.bias), M, d)
             # x_mid = x_in + out_proj(attention(qkv(LN1(x_in))))
             _to_bf16(dx, dy)
-            dwo, dbo = zeros(d, d), zeros(d)
-            _wgrad(dy, s["att"], dwo, M, d, d)
-            _colsum(dy, dbo, M, d)
+            _wgrad(dy, s["att"], gbuf(a.out_proj.weight), M, d, d)
+            _colsum(dy, gbuf(a.out_proj.bias), M, d)
             _gemm(dy, w["woT"], None, datt, M, d, d, d, d, 0)
             _ck(lib.bd_attention_bwd(_lib.ptr(s["qkv"]), _lib.ptr(keymask), _lib.ptr(s["att"]), _lib.ptr(datt),
                                      _lib.ptr(s["lse"]), _lib.ptr(delta), _lib.ptr(dqkv), B, L, H, d // H, _s()),
                 "bd_attention_bwd")
-            dwqkv, dbqkv = zeros(3 * d, d), zeros(3 * d)
-            _wgrad(dqkv, s["h1"], dwqkv, M, 3 * d, d)
-            _colsum(dqkv, dbqkv, M, 3 * d)
+            for i, proj in enumerate((a.q_proj, a.k_proj, a.v_proj)):      # column slices of the stacked dqkv
+                sl = dqkv[:, i * d:(i + 1) * d]
+                _wgrad(sl, s["h1"], gbuf(proj.weight), M, d, d)
+                _colsum(sl, gbuf(proj.bias), M, d)
             _gemm(dqkv, w["wqkvT"], None, dh, M, d, d, 3 * d, d, 0)
-            dg1, dbt1 = zeros(d), zeros(d)
-            _ln_bwd(dh, s["x_in"], s["st1"], blk.norm1.weight, dx, dx, dg1, dbt1, M, d)
-            a = blk.attn
-            grads[a.q_proj.weight], grads[a.k_proj.weight], grads[a.v_proj.weight] = dwqkv[:d], dwqkv[d:2 * d], dwqkv[2 * d:]
-            grads[a.q_proj.bias], grads[a.k_proj.bias], grads[a.v_proj.bias] = dbqkv[:d], dbqkv[d:2 * d], dbqkv[2 * d:]
-            grads[a.out_proj.weight], grads[a.out_proj.bias] = dwo, dbo
-            grads[blk.ffn.fc1.weight], grads[blk.ffn.fc1.bias] = dw1, db1
-            grads[blk.ffn.fc2.weight], grads[blk.ffn.fc2.bias] = dw2, db2
-            grads[blk.norm1.weight], grads[blk.norm1.bias] = dg1, dbt1
-            grads[blk.norm2.weight], grads[blk.norm2.bias] = dg2, dbt2
-        dtok = zeros(*model.token_embedding.weight.shape)
-        dpos = zeros(*model.position_embedding.weight.shape)
-        dtim = zeros(*model.timestep_embedding.weight.shape)
-        _ck(lib.bd_embed_bwd(_lib.ptr(dx), _lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(dtok), _lib.ptr(dpos),
-                             _lib.ptr(dtim), B, L, d, int(model.pad_token_id), _s()), "bd_embed_bwd")
-        grads[model.token_embedding.weight] = dtok
-        grads[model.position_embedding.weight] = dpos
-        grads[model.timestep_embedding.weight] = dtim
+            _ln_bwd(dh, s["x_in"], s["st1"], blk.norm1.weight, dx, dx, gbuf(blk.norm1.weight), gbuf(blk.norm1.bias), M, d)
+        _ck(lib.bd_embed_bwd(_lib.ptr(dx), _lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(gbuf(model.token_embedding.weight)),
+                             _lib.ptr(gbuf(model.position_embedding.weight)),
+                             _lib.ptr(gbuf(model.timestep_embedding.weight)), B, L, d, int(model.pad_token_id), _s()),
+            "bd_embed_bwd")
         out = [None, None, None, None]
-        for p in model.parameters():
+        for p in params:
             g = grads.get(p)
             out.append(g if (g is not None and p.requires_grad) else None)
         ctx.saved = None

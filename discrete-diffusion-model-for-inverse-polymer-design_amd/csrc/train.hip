@@ -79,19 +79,24 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
 
 // =====================================================================================
 // LayerNorm backward: dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma;
-// dgamma += sum dy * xhat, dbeta += sum dy. One wave per row, 8 rows per wave.
+// dgamma += sum dy * xhat, dbeta += sum dy. One wave per row, 16 rows per wave, 8 waves per workgroup;
+// the parameter gradients are summed over the workgroup's 128 rows in LDS before they go to
+// memory, so each address receives one atomic per 128 rows.
 // =====================================================================================
 template <int NV>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short* __restrict__ dy,
+__global__ __launch_bounds__(512) void layernorm_bwd_kernel(const unsigned short* __restrict__ dy,
                                                             const float* __restrict__ x,
                                                             const float* __restrict__ stats,
                                                             const float* __restrict__ gamma,
                                                             const float* dres, float* dx,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             int M, int d) {
-  constexpr int RPW = 8;
+  constexpr int RPW = 16;
+  extern __shared__ float red[];   // [2][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = d / 4;
+  for (int i = threadIdx.x; i < 2 * d; i += 512) red[i] = 0.f;
+  __syncthreads();
   f32x4 gm[NV], ag[NV], ab[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
     ag[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     ab[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  const int row0 = (blockIdx.x * 4 + wave) * RPW;
+  const int row0 = (blockIdx.x * 8 + wave) * RPW;
   for (int rr = 0; rr < RPW; ++rr) {
     const int row = row0 + rr;
     if (row >= M) break;
@@ -153,10 +158,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
     if (i < nv) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        atomicAdd(dgamma + 4 * i + e, ag[j][e]);
-        atomicAdd(dbeta + 4 * i + e, ab[j][e]);
+        atomicAdd(red + 4 * i + e, ag[j][e]);
+        atomicAdd(red + d + 4 * i + e, ab[j][e]);
       }
     }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < d; i += 512) {
+    atomicAdd(dgamma + i, red[i]);
+    atomicAdd(dbeta + i, red[d + i]);
   }
 }
 
@@ -269,25 +279,42 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const unsigned short* __r
     }
 }
 
-// out[n] += sum_m dY[m, n]   (bias gradients)
+// out[n] += sum_m dY[m, n]   (bias gradients). A workgroup owns 64 columns x up to 512 rows:
+// thread = (8-column group, row lane); a row lane walks its rows 32 apart, the 32 row lanes are
+// summed in LDS, then 64 atomics per workgroup go to memory.
+constexpr int CS_ROWS = 512;
 __global__ __launch_bounds__(256) void colsum_kernel(const unsigned short* __restrict__ dY, int ld,
-                                                     float* __restrict__ out, int M, int N, int rows_per_block) {
-  const int m0 = blockIdx.x * rows_per_block;
-  int m1 = m0 + rows_per_block;
-  m1 = m1 < M ? m1 : M;
-  for (int c8 = threadIdx.x; c8 < N / 8; c8 += 256) {
+                                                     float* __restrict__ out, int M, int N) {
+  __shared__ float red[64];
+  const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int col = blockIdx.x * 64 + cg * 8;
+  const int m0 = blockIdx.y * CS_ROWS;
+  const int m1 = m0 + CS_ROWS < M ? m0 + CS_ROWS : M;
+  if (threadIdx.x < 64) red[threadIdx.x] = 0.f;
+  __syncthreads();
+  if (col < N) {
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int m = m0; m < m1; ++m) {
-      const u32x4 w = *(const u32x4*)(dY + (size_t)m * ld + c8 * 8);
+#pragma unroll 4
+    for (int m = m0 + rl; m < m1; m += 32) {
+      const u32x4 w = *(const u32x4*)(dY + (size_t)m * ld + col);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         s[2 * e] += __uint_as_float(w[e] << 16);
         s[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
       }
     }
+    // the 8 row lanes of a wave that share a column group sit 8 lanes apart
 #pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(out + c8 * 8 + e, s[e]);
+    for (int e = 0; e < 8; ++e) {
+      float v = s[e];
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if ((threadIdx.x & 63) < 8) atomicAdd(red + cg * 8 + e, v);
+    }
   }
+  __syncthreads();
+  if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < N) atomicAdd(out + blockIdx.x * 64 + threadIdx.x, red[threadIdx.x]);
 }
 
 // =====================================================================================
@@ -636,15 +663,16 @@ extern "C" int bd_layernorm_bwd(const void* dy_bf16, const float* x, const float
                                 void* stream) {
   BD_REQUIRE(dy_bf16 && x && stats && gamma && dx && dgamma && dbeta, "bd_layernorm_bwd: null operand");
   BD_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 4096, "bd_layernorm_bwd: bad shape M=%d d=%d", M, d);
-  dim3 grid((M + 31) / 32), block(256);
+  dim3 grid((M + 127) / 128), block(512);
+  const size_t lds = 2 * (size_t)d * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   const unsigned short* dy = (const unsigned short*)dy_bf16;
   const int nv = (d / 4 + 63) / 64;
-  if (nv <= 1) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, block, 0, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d);
-  else if (nv <= 2) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, block, 0, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d);
-  else if (nv <= 4) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, 0, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d);
-  else if (nv <= 8) hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, block, 0, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d);
-  else hipLaunchKernelGGL(layernorm_bwd_kernel<16>, grid, block, 0, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d);
+  if (nv <= 1) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, block, lds, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d);
+  else if (nv <= 2) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, block, lds, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d);
+  else if (nv <= 4) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, lds, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d);
+  else if (nv <= 8) hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, block, lds, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d);
+  else hipLaunchKernelGGL(layernorm_bwd_kernel<16>, grid, block, lds, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d);
   return bd_check_launch("bd_layernorm_bwd");
 }
 
@@ -668,9 +696,8 @@ extern "C" int bd_gemm_wgrad_bf16(const void* dY, int ldy, const void* X, int ld
 
 extern "C" int bd_colsum_bf16(const void* dY, int ld, float* out, int M, int N, void* stream) {
   BD_REQUIRE(dY && out && M > 0 && N > 0 && N % 8 == 0 && ld >= N && ld % 8 == 0, "bd_colsum_bf16: bad argument");
-  const int rows = 128;
-  hipLaunchKernelGGL(colsum_kernel, dim3((M + rows - 1) / rows), dim3(256), 0, (hipStream_t)stream,
-                     (const unsigned short*)dY, ld, out, M, N, rows);
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, (M + CS_ROWS - 1) / CS_ROWS), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)dY, ld, out, M, N);
   return bd_check_launch("bd_colsum_bf16");
 }
 

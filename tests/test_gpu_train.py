@@ -260,6 +260,31 @@ def test_training_forward_backward_matches_oracle_autograd(gpu_device, name):
     assert model.backbone.position_embedding.weight.grad[ids.shape[1]:].abs().max().item() == 0.0
 
 
+def test_backward_into_bound_gradients_equals_autograd_accumulation(gpu_device):
+    """With .grad tensors already bound (FlatAdamW) the backward kernels add straight into them;
+    the result must equal what autograd's own accumulation gives, including over two micro-steps."""
+    dev = gpu_device
+    cfg, model, sd, ids, attn, t = _grad_setup("tiny_h2", dev)
+    model.train()
+    u = torch.rand(ids.shape, generator=torch.Generator().manual_seed(1))
+
+    def fwd_bwd():
+        noisy, ind = model.forward_process(ids.to(dev), t.to(dev), attn.to(dev), uniforms=u.to(dev))
+        logits = model.backbone(noisy, t.to(dev), attn.to(dev))
+        model._compute_loss(logits, ids.to(dev), ind, attn.to(dev)).backward()
+
+    fwd_bwd()                                              # .grad is None: autograd accumulates
+    ref = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    opt = FlatAdamW(model.parameters(), lr=1e-3)          # binds .grad to the flat buffer
+    opt.zero_grad()
+    fwd_bwd()
+    fwd_bwd()                                              # second micro-step accumulates on top
+    for k, p in model.named_parameters():
+        # atomic accumulation order differs between launches: compare with a small tolerance
+        assert rel(p.grad.cpu(), 2.0 * ref[k].cpu()) < 1e-4 or ref[k].abs().max().item() < 1e-12, k
+    assert opt.flat_grad.data_ptr() == next(iter(model.parameters())).grad.data_ptr()
+
+
 def test_training_steps_follow_fp32_reference_trajectory(gpu_device):
     """Five optimizer steps (corruption, forward, backward, clip 1.0, AdamW) on the GPU next to the
     same five steps of the fp32 CPU restatement with torch.optim.AdamW: losses stay within bf16
