@@ -105,6 +105,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const f32x4 v = *(const f32x4*)(xr + 32 * T + 8 * q);
         acc[T][4 * q + 0] = v[0]; acc[T][4 * q + 1] = v[1]; acc[T][4 * q + 2] = v[2]; acc[T][4 * q + 3] = v[3];
       }
+    // the rows live in accumulation registers from here on (without this hint the compiler keeps
+    // all of them in ordinary VGPRs through the LayerNorm and spills about a hundred)
+#pragma unroll
+    for (int T = 0; T < NT32; ++T) asm volatile("" : "+a"(acc[T]));
   }
 #pragma unroll
   for (int u = 0; u < 5; ++u) issue_unit(u);            // F >= 96: the first five units exist
