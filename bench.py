@@ -208,6 +208,17 @@ def main():
         n_dom, ms_dom, fl_dom = prof[dom]
         dom_tflops = fl_dom / (ms_dom * 1e-3) / 1e12
         step_ms = 1e3 * elapsed
+        # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process, so
+        # the figure comes from the committed rocprofv3 --pmc passes (profiles/r1_pmc_traffic.json)
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")) as fh:
+                tj = json.load(fh)
+            ent = tj["kernels"].get(kinds[dom].split(" ")[0])
+            if ent and B * L == 4096 * 128:
+                traffic, traffic_src = ent["traffic_bytes"], tj["source"]
+        except (OSError, ValueError, KeyError):
+            pass
         out = {
             "metric": "generated sequences/sec (Bi_Diffusion_SMILES reverse sampling, 100 steps, L=128)",
             "value": value, "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -220,7 +231,7 @@ def main():
                        "batch_per_gpu": B, "seq_len": L, "diffusion_steps": T, "sharding": f"{world} x independent batches"},
             "roofline": {"bound": "mfma", "kernel": kinds[dom],
                          "achieved": dom_tflops, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": dom_tflops / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                         "frac": dom_tflops / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "launches": n_dom, "avg_launch_ms": ms_dom / n_dom, "flops_per_launch": fl_dom / n_dom,
                          "share_of_timed_region": ms_dom / step_ms},
             "kernels": {kinds[k].split(" ")[0]: {"launches": v[0], "avg_launch_ms": v[1] / v[0],
