@@ -53,6 +53,7 @@ class BackboneDesc(C.Structure):
         ("lnf_g", VP), ("lnf_b", VP),
         ("w_out", VP),
         ("layers", C.POINTER(LayerWeights)),
+        ("attn_width", C.c_int),
     ]
 
 

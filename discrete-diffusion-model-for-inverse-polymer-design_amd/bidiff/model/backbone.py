@@ -152,26 +152,52 @@ class DiffusionBackbone(nn.Module):
 
         layers = (_lib.LayerWeights * max(1, self.num_layers))()
         L_ = _lib.lib()
+        # head sizes the attention kernels do not have (e.g. 48) are zero-padded to 32 / 64 / 128: extra
+        # q / k components add nothing to the scores, extra v components meet zero columns of out_proj;
+        # the q rows absorb sqrt(padded / true) because the kernel scales by 1 / sqrt(padded)
+        H = self.num_heads
+        dh = d // H
+        dhp = dh if dh in (32, 64, 128) else (32 if dh < 32 else 64 if dh < 64 else 128)
+        if dh > 128:
+            raise NotImplementedError("bidiff attention kernels support head_dim <= 128")
+        aw = H * dhp
+        if aw % 128:
+            raise NotImplementedError(f"bidiff: num_heads * padded head_dim = {aw} must be a multiple of 128")
+
+        def pad_rows(w):       # [H*dh, ...] -> [H*dhp, ...]
+            if dhp == dh:
+                return w
+            out = w.new_zeros((H, dhp) + tuple(w.shape[1:]))
+            out[:, :dh] = w.view((H, dh) + tuple(w.shape[1:]))
+            return out.view((H * dhp,) + tuple(w.shape[1:]))
+
+        qfix = math.sqrt(dhp / dh)
         with torch.no_grad():
             for i, blk in enumerate(self.layers):
                 a = blk.attn
-                wqkv = bf(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0))
-                bqkv = f32(torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], dim=0))
+                wq32 = torch.cat([pad_rows(a.q_proj.weight.float() * qfix), pad_rows(a.k_proj.weight.float()),
+                                  pad_rows(a.v_proj.weight.float())], dim=0)
+                bq32 = torch.cat([pad_rows(a.q_proj.bias.float() * qfix), pad_rows(a.k_proj.bias.float()),
+                                  pad_rows(a.v_proj.bias.float())], dim=0)
+                wqkv = bf(wq32)
+                bqkv = f32(bq32)
+                wo32 = a.out_proj.weight.float()
+                if dhp != dh:
+                    wo32 = pad_rows(wo32.t().contiguous()).t().contiguous()       # zero input columns
                 lw = layers[i]
                 lw.ln1_g = f32(blk.norm1.weight).data_ptr(); lw.ln1_b = f32(blk.norm1.bias).data_ptr()
                 lw.w_qkv = wqkv.data_ptr(); lw.b_qkv = bqkv.data_ptr()
-                lw.w_o = bf(a.out_proj.weight).data_ptr(); lw.b_o = f32(a.out_proj.bias).data_ptr()
+                lw.w_o = bf(wo32).data_ptr(); lw.b_o = f32(a.out_proj.bias).data_ptr()
                 lw.ln2_g = f32(blk.norm2.weight).data_ptr(); lw.ln2_b = f32(blk.norm2.bias).data_ptr()
                 lw.w_fc1 = bf(blk.ffn.fc1.weight).data_ptr(); lw.b_fc1 = f32(blk.ffn.fc1.bias).data_ptr()
                 lw.w_fc2 = bf(blk.ffn.fc2.weight).data_ptr(); lw.b_fc2 = f32(blk.ffn.fc2.bias).data_ptr()
                 # LayerNorm folded into the following projection: LN(x) W^T + b =
                 # ((x - mean) * rstd) (W * gamma)^T + (b + W beta)   (fp32 fold, then one bf16 rounding)
-                wq32 = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0).float()
                 lw.w_qkv_ln = bf(wq32 * blk.norm1.weight.float()[None, :]).data_ptr()
                 lw.b_qkv_ln = f32(bqkv + wq32 @ blk.norm1.bias.float()).data_ptr()
                 # weight stream of the fused attention block: q rows (and bias) also carry the
                 # softmax scale log2(e) / sqrt(head_dim), see attn_block.hip
-                if L_.bd_attn_block_supported(d, self.num_heads, 1):
+                if dhp == dh and L_.bd_attn_block_supported(d, self.num_heads, 1):
                     sc = math.log2(math.e) / math.sqrt(d // self.num_heads)
                     wa = (wq32 * blk.norm1.weight.float()[None, :]).clone()
                     ba = (bqkv + wq32 @ blk.norm1.bias.float()).clone()
@@ -213,6 +239,7 @@ class DiffusionBackbone(nn.Module):
             desc.lnf_b = f32(self.final_norm.bias).data_ptr()
             desc.w_out = w_out.data_ptr()
             desc.layers = C.cast(layers, C.POINTER(_lib.LayerWeights))
+            desc.attn_width = aw
         pk.key, pk.tensors, pk.layers, pk.desc, pk.w_out = key, keep, layers, desc, w_out
         return pk
 

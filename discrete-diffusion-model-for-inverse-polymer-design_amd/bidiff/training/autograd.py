@@ -52,20 +52,41 @@ def _to_bf16(x, out):
 
 
 class _TrainWeights:
-    """bf16 copies (and transposes for the data-gradient GEMMs) of the current parameters."""
+    """bf16 copies (and transposes for the data-gradient GEMMs) of the current parameters. Head sizes
+    the attention kernels do not have (e.g. 48) are zero-padded to 32 / 64 / 128 (``dhp``); the q rows
+    absorb sqrt(dhp / dh) because the kernels scale by 1 / sqrt(dhp)."""
 
     def __init__(self, model):
-        d, V = model.hidden_size, model.vocab_size
+        d, V, H = model.hidden_size, model.vocab_size, model.num_heads
         bf = torch.bfloat16
+        dh = d // H
+        if dh > 128:
+            raise NotImplementedError("bidiff attention kernels support head_dim <= 128")
+        self.dh = dh
+        self.dhp = dhp = dh if dh in (32, 64, 128) else (32 if dh < 32 else 64 if dh < 64 else 128)
+        self.aw = aw = H * dhp
+        if aw % 128:
+            raise NotImplementedError(f"bidiff: num_heads * padded head_dim = {aw} must be a multiple of 128")
+        self.qfix = qfix = (dhp / dh) ** 0.5
+
+        def pad_rows(w):       # [H*dh, ...] -> [H*dhp, ...]
+            if dhp == dh:
+                return w
+            out = w.new_zeros((H, dhp) + tuple(w.shape[1:]))
+            out[:, :dh] = w.view((H, dh) + tuple(w.shape[1:]))
+            return out.view((aw,) + tuple(w.shape[1:]))
+
         self.layers = []
         with torch.no_grad():
             for blk in model.layers:
                 a = blk.attn
-                wqkv = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0)
+                wqkv = torch.cat([pad_rows(a.q_proj.weight * qfix), pad_rows(a.k_proj.weight), pad_rows(a.v_proj.weight)], 0)
+                bqkv = torch.cat([pad_rows(a.q_proj.bias * qfix), pad_rows(a.k_proj.bias), pad_rows(a.v_proj.bias)], 0)
+                wo = a.out_proj.weight if dhp == dh else pad_rows(a.out_proj.weight.t().contiguous()).t()
                 self.layers.append({
                     "wqkv": wqkv.to(bf).contiguous(), "wqkvT": wqkv.t().to(bf).contiguous(),
-                    "bqkv": torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0).float().contiguous(),
-                    "wo": a.out_proj.weight.to(bf).contiguous(), "woT": a.out_proj.weight.t().to(bf).contiguous(),
+                    "bqkv": bqkv.float().contiguous(),
+                    "wo": wo.to(bf).contiguous(), "woT": wo.t().to(bf).contiguous(),
                     "w1": blk.ffn.fc1.weight.to(bf).contiguous(), "w1T": blk.ffn.fc1.weight.t().to(bf).contiguous(),
                     "w2": blk.ffn.fc2.weight.to(bf).contiguous(), "w2T": blk.ffn.fc2.weight.t().to(bf).contiguous(),
                 })
@@ -96,6 +117,7 @@ class _BackboneFn(torch.autograd.Function):
         bf = torch.bfloat16
         eps = float(model.final_norm.eps)
         tw = _train_weights(model)
+        aw = tw.aw
         x = torch.empty(M, d, device=dev)
         _ck(lib.bd_embed(_lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(model.token_embedding.weight),
                          _lib.ptr(model.position_embedding.weight), _lib.ptr(model.timestep_embedding.weight),
@@ -106,14 +128,14 @@ class _BackboneFn(torch.autograd.Function):
             s["st1"] = torch.empty(M, 2, device=dev)
             s["h1"] = torch.empty(M, d, dtype=bf, device=dev)
             _ln(x, blk.norm1.weight, blk.norm1.bias, s["h1"], s["st1"], M, d, eps)
-            s["qkv"] = torch.empty(M, 3 * d, dtype=bf, device=dev)
-            _gemm(s["h1"], w["wqkv"], w["bqkv"], s["qkv"], M, 3 * d, 3 * d, d, 3 * d, 0)
-            s["att"] = torch.empty(M, d, dtype=bf, device=dev)
+            s["qkv"] = torch.empty(M, 3 * aw, dtype=bf, device=dev)
+            _gemm(s["h1"], w["wqkv"], w["bqkv"], s["qkv"], M, 3 * aw, 3 * aw, d, 3 * aw, 0)
+            s["att"] = torch.empty(M, aw, dtype=bf, device=dev)
             s["lse"] = torch.empty(B, H, L, device=dev)
             _ck(lib.bd_attention_fwd(_lib.ptr(s["qkv"]), _lib.ptr(keymask), _lib.ptr(s["att"]), _lib.ptr(s["lse"]),
-                                     B, L, H, d // H, _s()), "bd_attention_fwd")
+                                     B, L, H, aw // H, _s()), "bd_attention_fwd")
             x_mid = torch.empty(M, d, device=dev)
-            _gemm(s["att"], w["wo"], blk.attn.out_proj.bias, x_mid, M, d, d, d, d, 2, aux_in=x)
+            _gemm(s["att"], w["wo"], blk.attn.out_proj.bias, x_mid, M, d, d, aw, d, 2, aux_in=x)
             s["x_mid"] = x_mid
             s["st2"] = torch.empty(M, 2, device=dev)
             s["h2"] = torch.empty(M, d, dtype=bf, device=dev)
@@ -173,16 +195,17 @@ class _BackboneFn(torch.autograd.Function):
             model.output_proj.weight.grad.add_(dwout[:V])
         else:
             grads[model.output_proj.weight] = dwout[:V]
-        dh = torch.empty(M, d, dtype=bf, device=dev)
-        _gemm(dl, tw.woutT, None, dh, M, d, d, tw.vpad, d, 0)
+        dh_buf = torch.empty(M, d, dtype=bf, device=dev)
+        _gemm(dl, tw.woutT, None, dh_buf, M, d, d, tw.vpad, d, 0)
         dx = torch.empty(M, d, device=dev)
-        _ln_bwd(dh, ctx.x_last, ctx.stf, model.final_norm.weight, None, dx, gbuf(model.final_norm.weight),
+        _ln_bwd(dh_buf, ctx.x_last, ctx.stf, model.final_norm.weight, None, dx, gbuf(model.final_norm.weight),
                 gbuf(model.final_norm.bias), M, d)
 
         dy = torch.empty(M, d, dtype=bf, device=dev)
         du = torch.empty(M, F, dtype=bf, device=dev)
-        datt = torch.empty(M, d, dtype=bf, device=dev)
-        dqkv = torch.empty(M, 3 * d, dtype=bf, device=dev)
+        aw, dh, dhp, padded = tw.aw, tw.dh, tw.dhp, tw.dhp != tw.dh
+        datt = torch.empty(M, aw, dtype=bf, device=dev)
+        dqkv = torch.empty(M, 3 * aw, dtype=bf, device=dev)
         delta = torch.empty(B, H, L, device=dev)
         for blk, w, s in zip(reversed(model.layers), reversed(tw.layers), reversed(ctx.saved)):
             a = blk.attn
@@ -193,22 +216,35 @@ class _BackboneFn(torch.autograd.Function):
             _gemm(dy, w["w2T"], None, du, M, F, F, d, F, 4, aux_in=s["u"])
             _wgrad(du, s["h2"], gbuf(blk.ffn.fc1.weight), M, F, d)
             _colsum(du, gbuf(blk.ffn.fc1.bias), M, F)
-            _gemm(du, w["w1T"], None, dh, M, d, d, F, d, 0)
-            _ln_bwd(dh, s["x_mid"], s["st2"], blk.norm2.weight, dx, dx, gbuf(blk.norm2.weight), gbuf(blk.norm2.bias), M, d)
+            _gemm(du, w["w1T"], None, dh_buf, M, d, d, F, d, 0)
+            _ln_bwd(dh_buf, s["x_mid"], s["st2"], blk.norm2.weight, dx, dx, gbuf(blk.norm2.weight), gbuf(blk.norm2.bias), M, d)
             # x_mid = x_in + out_proj(attention(qkv(LN1(x_in))))
             _to_bf16(dx, dy)
-            _wgrad(dy, s["att"], gbuf(a.out_proj.weight), M, d, d)
+            if not padded:
+                _wgrad(dy, s["att"], gbuf(a.out_proj.weight), M, d, d)
+            else:       # gradient of the zero-padded weight, real columns added to the parameter's
+                tmp = zeros(d, aw)
+                _wgrad(dy, s["att"], tmp, M, d, aw)
+                gbuf(a.out_proj.weight).view(d, H, dh).add_(tmp.view(d, H, dhp)[:, :, :dh])
             _colsum(dy, gbuf(a.out_proj.bias), M, d)
-            _gemm(dy, w["woT"], None, datt, M, d, d, d, d, 0)
+            _gemm(dy, w["woT"], None, datt, M, aw, aw, d, aw, 0)
             _ck(lib.bd_attention_bwd(_lib.ptr(s["qkv"]), _lib.ptr(keymask), _lib.ptr(s["att"]), _lib.ptr(datt),
-                                     _lib.ptr(s["lse"]), _lib.ptr(delta), _lib.ptr(dqkv), B, L, H, d // H, _s()),
+                                     _lib.ptr(s["lse"]), _lib.ptr(delta), _lib.ptr(dqkv), B, L, H, aw // H, _s()),
                 "bd_attention_bwd")
             for i, proj in enumerate((a.q_proj, a.k_proj, a.v_proj)):      # column slices of the stacked dqkv
-                sl = dqkv[:, i * d:(i + 1) * d]
-                _wgrad(sl, s["h1"], gbuf(proj.weight), M, d, d)
-                _colsum(sl, gbuf(proj.bias), M, d)
-            _gemm(dqkv, w["wqkvT"], None, dh, M, d, d, 3 * d, d, 0)
-            _ln_bwd(dh, s["x_in"], s["st1"], blk.norm1.weight, dx, dx, gbuf(blk.norm1.weight), gbuf(blk.norm1.bias), M, d)
+                sl = dqkv[:, i * aw:(i + 1) * aw]
+                if not padded:
+                    _wgrad(sl, s["h1"], gbuf(proj.weight), M, d, d)
+                    _colsum(sl, gbuf(proj.bias), M, d)
+                else:   # rows of the padded projection; the q rows were scaled by qfix in the forward
+                    tw_, tb_ = zeros(aw, d), zeros(aw)
+                    _wgrad(sl, s["h1"], tw_, M, aw, d)
+                    _colsum(sl, tb_, M, aw)
+                    f = tw.qfix if i == 0 else 1.0
+                    gbuf(proj.weight).view(H, dh, d).add_(tw_.view(H, dhp, d)[:, :dh], alpha=f)
+                    gbuf(proj.bias).view(H, dh).add_(tb_.view(H, dhp)[:, :dh], alpha=f)
+            _gemm(dqkv, w["wqkvT"], None, dh_buf, M, d, d, 3 * aw, d, 0)
+            _ln_bwd(dh_buf, s["x_in"], s["st1"], blk.norm1.weight, dx, dx, gbuf(blk.norm1.weight), gbuf(blk.norm1.bias), M, d)
         _ck(lib.bd_embed_bwd(_lib.ptr(dx), _lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(gbuf(model.token_embedding.weight)),
                              _lib.ptr(gbuf(model.position_embedding.weight)),
                              _lib.ptr(gbuf(model.timestep_embedding.weight)), B, L, d, int(model.pad_token_id), _s()),

@@ -15,8 +15,9 @@ Carve carve(const bd_backbone_desc& c, long long M) {
   long long off = 0;
   w.x = off;   off += align256(M * c.d * 4);        // residual stream fp32
   w.h = off;   off += align256(M * c.d * 2);        // LayerNorm output bf16
-  w.qkv = off; off += align256(M * 3 * c.d * 2);    // fused q|k|v bf16
-  w.att = off; off += align256(M * c.d * 2);        // attention output bf16
+  const long long aw = c.attn_width > 0 ? c.attn_width : c.d;
+  w.qkv = off; off += align256(M * 3 * aw * 2);     // fused q|k|v bf16 (heads padded to 32 / 64 / 128)
+  w.att = off; off += align256(M * aw * 2);         // attention output bf16
   w.ff = off;  off += align256(M * c.ffn * 2);      // GELU(fc1) bf16
   w.total = off;
   return w;
@@ -27,6 +28,8 @@ int check_desc(const bd_backbone_desc* d) {
   BD_REQUIRE(d->d > 0 && d->n_layers >= 0 && d->n_heads > 0 && d->ffn > 0 && d->vocab > 0,
              "backbone: bad dimensions");
   BD_REQUIRE(d->d % d->n_heads == 0, "backbone: hidden %d not divisible by heads %d", d->d, d->n_heads);
+  BD_REQUIRE(d->attn_width == 0 || (d->attn_width >= d->d && d->attn_width % (128 * 1) == 0 && d->attn_width % d->n_heads == 0),
+             "backbone: attn_width %d must be a multiple of 128 and of the head count, and >= hidden", d->attn_width);
   BD_REQUIRE(d->d % 128 == 0 && d->ffn % 128 == 0,
              "backbone: hidden (%d) and ffn (%d) sizes must be multiples of 128", d->d, d->ffn);
   BD_REQUIRE(d->vocab_pad % 128 == 0 && d->vocab_pad >= d->vocab, "backbone: vocab_pad must be a multiple of 128");
@@ -65,6 +68,7 @@ extern "C" int bd_backbone_forward(const bd_backbone_desc* desc, const long long
   void* att = ws + w.att;
   void* ff = ws + w.ff;
   const int d = c.d, F = c.ffn, Mi = (int)M;
+  const int aw = c.attn_width > 0 ? c.attn_width : d;   // q / k / v row width (padded heads)
 
   if ((rc = bd_embed(ids, timesteps, c.tok_emb, c.pos_emb, c.time_emb, x, B, L, d, stream))) return rc;
   // Fused kernels whenever the shapes allow: the whole attention block in one kernel per sequence
@@ -72,10 +76,10 @@ extern "C" int bd_backbone_forward(const bd_backbone_desc* desc, const long long
   // stream touches memory). Otherwise LayerNorm folded into the row-panel projection kernel, or
   // plain LayerNorm + tiled GEMMs. The residual projections of the unfused path use the tiled
   // GEMM, which is the faster one there.
-  const bool pan_qkv = bd_gemm_panel_supported(3 * d, d, 1) != 0;
+  const bool pan_qkv = bd_gemm_panel_supported(3 * aw, d, 1) != 0;
   const bool pan_fc1 = bd_gemm_panel_supported(F, d, 1) != 0;
   const bool fused_ffn = bd_ffn_fused_supported(d, F) != 0;
-  const bool fused_attn = bd_attn_block_supported(d, c.n_heads, L) != 0;
+  const bool fused_attn = aw == d && bd_attn_block_supported(d, c.n_heads, L) != 0;
   for (int i = 0; i < c.n_layers; ++i) {
     const bd_layer_weights& lw = c.layers[i];
     // ---- x += out_proj(attention(ln1(x)))
@@ -84,14 +88,14 @@ extern "C" int bd_backbone_forward(const bd_backbone_desc* desc, const long long
       if (rc) return rc;
     } else {
       if (pan_qkv && lw.w_qkv_ln && lw.b_qkv_ln) {
-        rc = bd_gemm_panel(x, lw.w_qkv_ln, lw.b_qkv_ln, qkv, nullptr, Mi, 3 * d, d, 3 * d, 0, 1, c.ln_eps, stream);
+        rc = bd_gemm_panel(x, lw.w_qkv_ln, lw.b_qkv_ln, qkv, nullptr, Mi, 3 * aw, d, 3 * aw, 0, 1, c.ln_eps, stream);
       } else {
         if ((rc = bd_layernorm(x, lw.ln1_g, lw.ln1_b, h, nullptr, nullptr, Mi, d, c.ln_eps, stream))) return rc;
-        rc = bd_gemm_bf16(h, lw.w_qkv, lw.b_qkv, qkv, Mi, 3 * d, 3 * d, d, 3 * d, 0, stream);
+        rc = bd_gemm_bf16(h, lw.w_qkv, lw.b_qkv, qkv, Mi, 3 * aw, 3 * aw, d, 3 * aw, 0, stream);
       }
       if (rc) return rc;
-      if ((rc = bd_attention_fwd(qkv, keymask, att, nullptr, B, L, c.n_heads, d / c.n_heads, stream))) return rc;
-      if ((rc = bd_gemm_bf16(att, lw.w_o, lw.b_o, x, Mi, d, d, d, d, 2, stream))) return rc;
+      if ((rc = bd_attention_fwd(qkv, keymask, att, nullptr, B, L, c.n_heads, aw / c.n_heads, stream))) return rc;
+      if ((rc = bd_gemm_bf16(att, lw.w_o, lw.b_o, x, Mi, d, d, aw, d, 2, stream))) return rc;
     }
     // ---- x += fc2(gelu(fc1(ln2(x))))
     if (fused_ffn && lw.ffn_pack && lw.b_fc1_ln) {

@@ -108,7 +108,8 @@ int bd_attn_block_fused(const float* x, float* out, const void* wpack, const flo
 /* Non-causal multi-head attention on the fused qkv rows [B*L, 3*H*head_dim] (bf16) with a
  * key-padding byte mask [B,L] (non-zero = visible; null = all visible). A query whose keys
  * are all masked gives an all-zero output row. out [B*L, H*head_dim] bf16; lse optional
- * [B,H,L] fp32. head_dim in {32, 64, 128}, any L.
+ * [B,H,L] fp32. head_dim in {32, 64, 128}, any L (other head sizes: zero-pad, see
+ * bd_backbone_desc.attn_width).
  * replaces F.scaled_dot_product_attention at src/model/backbone.py:54-67. */
 int bd_attention_fwd(const void* qkv, const unsigned char* keymask, void* out, float* lse, int B,
                      int L, int H, int head_dim, void* stream);
@@ -146,6 +147,11 @@ typedef struct bd_backbone_desc {
   const float* lnf_g; const float* lnf_b;
   const void* w_out;      /* [vocab_pad, d] bf16, rows >= vocab are zero */
   const bd_layer_weights* layers; /* HOST array of n_layers entries */
+  /* width of the q, k, v and attention-output rows: n_heads * (head_dim padded to 32 / 64 / 128);
+   * 0 = d. When larger than d (e.g. 8 heads of 48 at d = 384 -> 8 x 64 = 512) the caller pads the
+   * weights with zero rows / columns: w_qkv [3*attn_width, d], b_qkv [3*attn_width], w_o [d, attn_width],
+   * and pre-scales the q rows by sqrt(padded / true head_dim) (the kernel scales by 1/sqrt(padded)). */
+  int attn_width;
 } bd_backbone_desc;
 
 /* Bytes of device scratch bd_backbone_forward needs for a [B, L] batch. */

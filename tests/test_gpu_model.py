@@ -71,6 +71,29 @@ def test_small_config_logits_match_oracle(gpu_device):
         assert rel_err(got, ref) < BF16_TOL
 
 
+@pytest.mark.parametrize("hidden,heads,layers,ffn,B,L", [
+    (384, 8, 2, 1536, 4, 96),      # the reference's default model block: 8 heads of 48 (padded to 64 inside)
+    (256, 4, 2, 1024, 3, 128),     # the reference's "tiny" size: fused kernels with head_dim 64
+    (1024, 16, 2, 4096, 2, 512),   # scaled-up stress shape (d = 1024, L = 512): unfused kernels
+    (384, 3, 2, 1536, 3, 200),     # small backbone beyond 128 tokens: fused feed-forward, unfused attention
+])
+def test_other_architectures_match_oracle(gpu_device, hidden, heads, layers, ffn, B, L):
+    cfg = dict(RI.SMALL_CFG, hidden_size=hidden, num_heads=heads, num_layers=layers, ffn_hidden_size=ffn,
+               max_position_embeddings=max(256, L), dropout=0.0)
+    torch.manual_seed(1)
+    bb = DiffusionBackbone(**cfg).eval()
+    RI.perturb_state_dict(bb.state_dict(), 9)
+    sd = {k: v.clone() for k, v in bb.state_dict().items()}
+    ids, attn, t = RI.backbone_inputs(cfg, 4, B=B, L=L)
+    with torch.no_grad():
+        ref = BR.logits(sd, cfg, torch.from_numpy(ids), torch.from_numpy(t), torch.from_numpy(attn)).numpy()
+        bbg = bb.to(gpu_device)
+        got = bbg(torch.from_numpy(ids).to(gpu_device), torch.from_numpy(t).to(gpu_device),
+                  torch.from_numpy(attn).to(gpu_device)).cpu().numpy()
+    assert np.isfinite(got).all()
+    assert rel_err(got, ref) < BF16_TOL
+
+
 def test_cpu_tensors_fail_loudly():
     cfg, bb = tiny_model("tiny_h2")
     ids, attn, t = RI.backbone_inputs(cfg, 21)

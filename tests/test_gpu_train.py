@@ -260,6 +260,34 @@ def test_training_forward_backward_matches_oracle_autograd(gpu_device, name):
     assert model.backbone.position_embedding.weight.grad[ids.shape[1]:].abs().max().item() == 0.0
 
 
+def test_training_with_padded_heads_matches_oracle_autograd(gpu_device):
+    """8 heads of 48 (the reference's default block): the kernels run with heads zero-padded to 64;
+    loss and all parameter gradients must still match fp32 autograd of the CPU restatement."""
+    dev = gpu_device
+    cfg = dict(RI.SMALL_CFG, num_heads=8, num_layers=1, dropout=0.0)
+    torch.manual_seed(7)
+    bb = DiffusionBackbone(**cfg)
+    RI.perturb_state_dict(bb.state_dict(), 11)
+    model = DiscreteMaskingDiffusion(bb, num_steps=cfg["num_diffusion_steps"], mask_token_id=1, pad_token_id=0,
+                                     bos_token_id=2, eos_token_id=3)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    ids, attn, t = (torch.from_numpy(x) for x in RI.backbone_inputs(cfg, 33, B=6, L=24))
+    model = model.to(dev).train()
+    u = torch.rand(ids.shape, generator=torch.Generator().manual_seed(1))
+    noisy, ind = model.forward_process(ids.to(dev), t.to(dev), attn.to(dev), uniforms=u.to(dev))
+    loss = model._compute_loss(model.backbone(noisy, t.to(dev), attn.to(dev)), ids.to(dev), ind, attn.to(dev))
+    loss.backward()
+    ref_sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and k != "mask_schedule") for k, v in sd.items()}
+    rloss = BR.masked_ce(BR.logits(ref_sd, cfg, noisy.cpu(), t, attn, prefix="backbone."), ids, ind.cpu(), attn)
+    rloss.backward()
+    assert abs(loss.item() - rloss.item()) < 2e-2 * abs(rloss.item())
+    for k, p in model.named_parameters():
+        if k.endswith("k_proj.bias"):
+            continue        # true gradient is zero (softmax shift invariance)
+        cos = torch.nn.functional.cosine_similarity(p.grad.cpu().flatten(), ref_sd[k].grad.flatten(), dim=0).item()
+        assert rel(p.grad.cpu(), ref_sd[k].grad) < 1e-1 and cos > 0.995, (k, cos)
+
+
 def test_backward_into_bound_gradients_equals_autograd_accumulation(gpu_device):
     """With .grad tensors already bound (FlatAdamW) the backward kernels add straight into them;
     the result must equal what autograd's own accumulation gives, including over two micro-steps."""
