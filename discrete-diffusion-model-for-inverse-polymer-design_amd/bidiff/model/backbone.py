@@ -307,11 +307,24 @@ class DiffusionBackbone(nn.Module):
         return logits
 
     def get_hidden_states(self, input_ids, timesteps, attention_mask=None, layer_idx: int = -1):
-        """Final-norm hidden states [batch, seq_len, hidden] (reference backbone.py:259-299).
-        Only ``layer_idx == -1`` (all layers + final norm) is executed natively."""
-        if layer_idx != -1:
-            raise NotImplementedError("bidiff: intermediate-layer hidden states are not built yet")
+        """Hidden states [batch, seq_len, hidden] (reference backbone.py:259-299): ``layer_idx == -1``
+        gives the final-norm output of the whole stack, ``layer_idx = i`` the residual stream after
+        block i (no final norm)."""
         keymask = self._keymask_bytes(attention_mask, input_ids)
+        if layer_idx != -1:
+            if not 0 <= layer_idx < self.num_layers:
+                raise IndexError(f"layer_idx {layer_idx} out of range for {self.num_layers} layers")
+            timesteps = self._check_inputs(input_ids, timesteps)
+            B, L = input_ids.shape
+            pk = self.packed()
+            ws, need = self._workspace(pk, B, L, input_ids.device)
+            ids = input_ids.to(torch.long).contiguous()
+            out = torch.empty(B, L, self.hidden_size, dtype=torch.float32, device=input_ids.device)
+            rc = _lib.lib().bd_backbone_forward_layers(
+                C.byref(pk.desc), _lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(keymask), B, L, _lib.ptr(ws), need,
+                layer_idx + 1, _lib.ptr(out), _lib.stream_handle())
+            _lib.check(rc, "bd_backbone_forward_layers")
+            return out
         hidden, _ = self.run_forward(input_ids, timesteps, keymask, want_hidden=True, want_logits=False)
         return hidden.float()
 

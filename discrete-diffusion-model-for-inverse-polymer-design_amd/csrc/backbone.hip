@@ -44,10 +44,12 @@ extern "C" long long bd_backbone_workspace_bytes(const bd_backbone_desc* desc, i
   return carve(*desc, (long long)B * L).total;
 }
 
-extern "C" int bd_backbone_forward(const bd_backbone_desc* desc, const long long* ids,
-                                   const long long* timesteps, const unsigned char* keymask, int B,
-                                   int L, void* workspace, long long workspace_bytes, void* hidden_out,
-                                   float* logits_out, void* stream) {
+namespace {
+// n_run layers (n_run = n_layers: the whole network); resid_out (optional) receives the fp32 residual
+// stream after those layers; the final LayerNorm / vocabulary head run only when asked for.
+int forward_impl(const bd_backbone_desc* desc, const long long* ids, const long long* timesteps,
+                 const unsigned char* keymask, int B, int L, void* workspace, long long workspace_bytes,
+                 int n_run, float* resid_out, void* hidden_out, float* logits_out, void* stream) {
   int rc = check_desc(desc);
   if (rc != BD_OK) return rc;
   const bd_backbone_desc& c = *desc;
@@ -80,7 +82,7 @@ extern "C" int bd_backbone_forward(const bd_backbone_desc* desc, const long long
   const bool pan_fc1 = bd_gemm_panel_supported(F, d, 1) != 0;
   const bool fused_ffn = bd_ffn_fused_supported(d, F) != 0;
   const bool fused_attn = aw == d && bd_attn_block_supported(d, c.n_heads, L) != 0;
-  for (int i = 0; i < c.n_layers; ++i) {
+  for (int i = 0; i < n_run; ++i) {
     const bd_layer_weights& lw = c.layers[i];
     // ---- x += out_proj(attention(ln1(x)))
     if (fused_attn && lw.attn_pack && lw.b_q_attn && lw.b_o_fold) {
@@ -111,6 +113,11 @@ extern "C" int bd_backbone_forward(const bd_backbone_desc* desc, const long long
       if ((rc = bd_gemm_bf16(ff, lw.w_fc2, lw.b_fc2, x, Mi, d, d, F, d, 2, stream))) return rc;
     }
   }
+  if (resid_out != nullptr) {
+    if (hipMemcpyAsync(resid_out, x, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+      return bd_fail(BD_ERR_LAUNCH, "bd_backbone_forward_layers: copy of the residual stream failed");
+  }
+  if (hidden_out == nullptr && logits_out == nullptr) return BD_OK;
   void* hf = hidden_out ? hidden_out : h;
   if ((rc = bd_layernorm(x, c.lnf_g, c.lnf_b, hf, nullptr, nullptr, Mi, d, c.ln_eps, stream))) return rc;
   if (logits_out != nullptr) {
@@ -118,4 +125,26 @@ extern "C" int bd_backbone_forward(const bd_backbone_desc* desc, const long long
       return rc;
   }
   return BD_OK;
+}
+}  // namespace
+
+extern "C" int bd_backbone_forward(const bd_backbone_desc* desc, const long long* ids,
+                                   const long long* timesteps, const unsigned char* keymask, int B,
+                                   int L, void* workspace, long long workspace_bytes, void* hidden_out,
+                                   float* logits_out, void* stream) {
+  if (desc == nullptr) return bd_fail(BD_ERR_ARG, "backbone: null descriptor");
+  return forward_impl(desc, ids, timesteps, keymask, B, L, workspace, workspace_bytes, desc->n_layers, nullptr,
+                      hidden_out, logits_out, stream);
+}
+
+extern "C" int bd_backbone_forward_layers(const bd_backbone_desc* desc, const long long* ids,
+                                          const long long* timesteps, const unsigned char* keymask, int B,
+                                          int L, void* workspace, long long workspace_bytes, int n_run,
+                                          float* resid_out, void* stream) {
+  if (desc == nullptr) return bd_fail(BD_ERR_ARG, "backbone: null descriptor");
+  BD_REQUIRE(n_run >= 0 && n_run <= desc->n_layers, "bd_backbone_forward_layers: n_run=%d of %d layers", n_run,
+             desc->n_layers);
+  BD_REQUIRE(resid_out != nullptr, "bd_backbone_forward_layers: null output");
+  return forward_impl(desc, ids, timesteps, keymask, B, L, workspace, workspace_bytes, n_run, resid_out, nullptr,
+                      nullptr, stream);
 }

@@ -169,6 +169,14 @@ int bd_backbone_forward(const bd_backbone_desc* desc, const long long* ids,
                         void* workspace, long long workspace_bytes, void* hidden_out,
                         float* logits_out, void* stream);
 
+/* Embeddings + the first n_run blocks only; resid_out [B*L, d] fp32 receives the residual stream
+ * (no final LayerNorm). Replaces get_hidden_states(layer_idx = n_run - 1 >= 0),
+ * src/model/backbone.py:259-299. */
+int bd_backbone_forward_layers(const bd_backbone_desc* desc, const long long* ids,
+                               const long long* timesteps, const unsigned char* keymask, int B, int L,
+                               void* workspace, long long workspace_bytes, int n_run, float* resid_out,
+                               void* stream);
+
 /* bd_gemm_bf16 with the extra operands some epilogues take:
  *   epilogue 1: aux_out (optional) receives the bf16 pre-activation acc + bias (saved for backward)
  *   epilogue 2: aux_in (optional) is the fp32 residual input; out = aux_in + acc + bias

@@ -33,8 +33,9 @@ def attention(x, sd, prefix, num_heads, attention_mask):
     return F.linear(out, sd[f"{prefix}.out_proj.weight"], sd[f"{prefix}.out_proj.bias"])
 
 
-def hidden_states(sd, cfg, input_ids, timesteps, attention_mask=None, prefix="", eps=1e-5):
-    """Final-norm hidden states [B, L, d] (fp32)."""
+def hidden_states(sd, cfg, input_ids, timesteps, attention_mask=None, prefix="", eps=1e-5, layer_idx=-1):
+    """Hidden states [B, L, d] (fp32): final-norm output for ``layer_idx == -1``, otherwise the residual
+    stream after block ``layer_idx`` without the final norm (reference backbone.py:291-299)."""
     p = prefix
     B, L = input_ids.shape
     d = cfg["hidden_size"]
@@ -43,7 +44,7 @@ def hidden_states(sd, cfg, input_ids, timesteps, attention_mask=None, prefix="",
     pos = torch.arange(L, device=input_ids.device)
     x = (sd[p + "token_embedding.weight"][input_ids] + sd[p + "position_embedding.weight"][pos][None]
          + sd[p + "timestep_embedding.weight"][timesteps][:, None, :])
-    for i in range(cfg["num_layers"]):
+    for i in range(cfg["num_layers"] if layer_idx == -1 else layer_idx + 1):
         lp = f"{p}layers.{i}"
         h = F.layer_norm(x, (d,), sd[f"{lp}.norm1.weight"], sd[f"{lp}.norm1.bias"], eps)
         x = x + attention(h, sd, f"{lp}.attn", cfg["num_heads"], attention_mask)
@@ -51,6 +52,8 @@ def hidden_states(sd, cfg, input_ids, timesteps, attention_mask=None, prefix="",
         h = F.linear(h, sd[f"{lp}.ffn.fc1.weight"], sd[f"{lp}.ffn.fc1.bias"])
         h = F.gelu(h)
         x = x + F.linear(h, sd[f"{lp}.ffn.fc2.weight"], sd[f"{lp}.ffn.fc2.bias"])
+    if layer_idx != -1:
+        return x
     return F.layer_norm(x, (d,), sd[p + "final_norm.weight"], sd[p + "final_norm.bias"], eps)
 
 

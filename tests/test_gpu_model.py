@@ -94,6 +94,26 @@ def test_other_architectures_match_oracle(gpu_device, hidden, heads, layers, ffn
     assert rel_err(got, ref) < BF16_TOL
 
 
+def test_intermediate_hidden_states_match_oracle(gpu_device):
+    """get_hidden_states(layer_idx): residual stream after block i, no final norm (-1: final norm)."""
+    cfg = dict(RI.SMALL_CFG, num_layers=3, dropout=0.0)
+    torch.manual_seed(2)
+    bb = DiffusionBackbone(**cfg).eval()
+    RI.perturb_state_dict(bb.state_dict(), 13)
+    sd = {k: v.clone() for k, v in bb.state_dict().items()}
+    ids, attn, t = (torch.from_numpy(x) for x in RI.backbone_inputs(cfg, 8, B=5, L=64))
+    bbg = bb.to(gpu_device)
+    with torch.no_grad():
+        for idx in (0, 1, 2, -1):
+            ref = BR.hidden_states(sd, cfg, ids, t, attn, layer_idx=idx).numpy()
+            got = bbg.get_hidden_states(ids.to(gpu_device), t.to(gpu_device), attn.to(gpu_device), layer_idx=idx)
+            assert got.dtype == torch.float32 and tuple(got.shape) == ref.shape
+            valid = attn.bool().numpy()           # padded rows are not specified
+            assert rel_err(got.cpu().numpy()[valid], ref[valid]) < BF16_TOL, idx
+        with pytest.raises(IndexError):
+            bbg.get_hidden_states(ids.to(gpu_device), t.to(gpu_device), attn.to(gpu_device), layer_idx=3)
+
+
 def test_cpu_tensors_fail_loudly():
     cfg, bb = tiny_model("tiny_h2")
     ids, attn, t = RI.backbone_inputs(cfg, 21)
