@@ -19,21 +19,17 @@
 // units: GEMM1 (d/16 MFMAs), GELU in registers, GEMM2 (d/16 MFMAs) into the residual accumulators.
 #include "bd_common.h"
 #include "bd_prof.h"
-#include <type_traits>
+#include "fused_phases.h"
 
 namespace {
 
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void glb_void;
+using namespace bdf;
 
 struct FfnArgs {
   const float* x;               // [M, d] residual stream in
   float* out;                   // [M, d] residual stream out (may equal x)
-  const unsigned char* wpack;   // packed weight stream (bd_ffn_pack_weights)
-  const float* b1;              // [F] first bias with LayerNorm beta folded in
-  const float* b2;              // [d]
-  int M, F;
-  float eps;
+  FfnPhase ph;
+  int M;
   int stagger_blocks;           // workgroups of the first round (= CUs), which start phase-shifted
   int stagger_units;            // phase step in units of ~1 us
 };
@@ -53,242 +49,18 @@ struct FfnArgs {
 // 0.5 erf(x / sqrt 2) on |x| <= 4; past that the product overshoots +-0.5 and the clamp saturates
 // it. |error| < 2e-4 absolute, below the bf16 rounding of the activations that matter. No
 // transcendental and only scalar fp32 FMAs (packed fp32 math is slow next to MFMAs).
-struct Gelu2 { float x0, x1, s0, s1, p0, p1; };
-
+// (The phase itself lives in fused_phases.h.)
 template <int NT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void ffn_fused_kernel(FfnArgs p) {
   constexpr int D = NT * 16;
-  constexpr int NT32 = NT / 2;                // 32-feature tiles of the residual row
-  constexpr int UNIT = NT * 1024;             // unit 2 j = W1 of chunk j, unit 2 j + 1 = W2 of chunk j
-  constexpr int RING = 6;
-  constexpr int PER_UNIT = NT / 4;
-  constexpr int NF = 2 * NT;                  // fragments (= MFMAs) per chunk
-  constexpr int FB = 8;                       // fragment read batch
-  static_assert(NT % FB == 0, "fragment batches must tile both GEMMs");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  float* const sb1 = (float*)(smem + RING * UNIT);     // F + 32 floats
-  typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
-  typedef const __attribute__((address_space(3))) f32x4* lds_f4;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: LDS-DMA targets stay scalar
-  const int h = lane >> 5, c = lane & 31;
-  const int nch = p.F >> 5;
-  const int nunits = 2 * nch;
-  const int m = blockIdx.x * 128 + wave * 32 + c;
-
-  auto issue_unit = [&](int u) {
-    const unsigned char* src = p.wpack + (size_t)u * UNIT + lane * 16;
-    unsigned char* dst = smem + (u % RING) * UNIT;
-#pragma unroll
-    for (int i = 0; i < PER_UNIT; ++i) {
-      const int f = wave + 4 * i;
-      __builtin_amdgcn_global_load_lds((glb_void*)(src + f * 1024), (lds_void*)(dst + f * 1024), 16, 0, 0);
-    }
-  };
-
-  // The first workgroup of every CU starts a little later than its neighbours' (16 phases): all
-  // workgroups take the same time, so without this every CU would load its rows, compute and
-  // store in lockstep, and the memory system would alternate between overload and idleness.
-  if ((int)blockIdx.x < p.stagger_blocks) {
-    const int phase = (blockIdx.x >> 3) & 15;
-    for (int k = 0; k < phase * p.stagger_units; ++k) __builtin_amdgcn_s_sleep(32);
-  }
-
-  f32x16 acc[NT32];
-  {
-    const float* xr = p.x + (size_t)(m < p.M ? m : p.M - 1) * D + 4 * h;
-#pragma unroll
-    for (int T = 0; T < NT32; ++T)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 v = *(const f32x4*)(xr + 32 * T + 8 * q);
-        acc[T][4 * q + 0] = v[0]; acc[T][4 * q + 1] = v[1]; acc[T][4 * q + 2] = v[2]; acc[T][4 * q + 3] = v[3];
-      }
-    // the rows live in accumulation registers from here on (without this hint the compiler keeps
-    // all of them in ordinary VGPRs through the LayerNorm and spills about a hundred)
-#pragma unroll
-    for (int T = 0; T < NT32; ++T) asm volatile("" : "+a"(acc[T]));
-  }
-#pragma unroll
-  for (int u = 0; u < 5; ++u) issue_unit(u);            // F >= 96: the first five units exist
-  for (int i = tid; i < p.F + 32; i += 256) sb1[i] = i < p.F ? p.b1[i] : 0.f;
-
-  // ---- LayerNorm -> bf16 B operands (gamma / beta are folded into W1 and b1)
-  bf16x8 xln[NT];
-  {
-    float s = 0.f;
-#pragma unroll
-    for (int T = 0; T < NT32; ++T)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s += acc[T][r];
-    s += __shfl_xor(s, 32, 64);
-    const float mean = s * (1.0f / D);
-    float q = 0.f;
-#pragma unroll
-    for (int T = 0; T < NT32; ++T)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { const float dv = acc[T][r] - mean; q += dv * dv; }
-    q += __shfl_xor(q, 32, 64);
-    const float rstd = rsqrtf(q * (1.0f / D) + p.eps);
-#pragma unroll
-    for (int kb = 0; kb < NT; ++kb) {
-      bf16x8 f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = (__bf16)((acc[kb >> 1][8 * (kb & 1) + e] - mean) * rstd);
-      xln[kb] = f;
-    }
-  }
-
-  const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem + lane * 16;
-  const unsigned ldsb = (unsigned)(size_t)(lds_void*)sb1 + 16 * h;
-
-  f32x16 hn_cur, hn_next;      // GEMM1 results of chunk j and j + 1 (rows = hidden units of the chunk)
-  bf16x8 hb[2], hb0_next;      // GELU(hn_cur) as the two B operands of GEMM2; first half of the next
-  Gelu2 gs;
-
-  // GELU part g (0..47): pair g / 6 = registers 2 pair, 2 pair + 1 of the source tile, in six parts
-  auto gelu_part = [&](int g, const f32x16& src, bf16x8& dst) {
-    const int pair = g / 6, part = g % 6;
-    if (part == 0) {
-      gs.x0 = src[2 * pair]; gs.x1 = src[2 * pair + 1];
-      gs.s0 = fminf(gs.x0 * gs.x0, 16.0f); gs.s1 = fminf(gs.x1 * gs.x1, 16.0f);
-      asm volatile("" : "+v"(gs.s0), "+v"(gs.s1));
-    } else if (part == 1) {
-      gs.p0 = gs.s0 * -1.903182666e-09f + 1.410586241e-07f; gs.p1 = gs.s1 * -1.903182666e-09f + 1.410586241e-07f;
-      gs.p0 = gs.p0 * gs.s0 + -4.565313249e-06f;            gs.p1 = gs.p1 * gs.s1 + -4.565313249e-06f;
-      asm volatile("" : "+v"(gs.p0), "+v"(gs.p1));
-    } else if (part == 2) {
-      gs.p0 = gs.p0 * gs.s0 + 8.634553992e-05f;  gs.p1 = gs.p1 * gs.s1 + 8.634553992e-05f;
-      gs.p0 = gs.p0 * gs.s0 + -1.085383136e-03f; gs.p1 = gs.p1 * gs.s1 + -1.085383136e-03f;
-      asm volatile("" : "+v"(gs.p0), "+v"(gs.p1));
-    } else if (part == 3) {
-      gs.p0 = gs.p0 * gs.s0 + 9.789848745e-03f;  gs.p1 = gs.p1 * gs.s1 + 9.789848745e-03f;
-      gs.p0 = gs.p0 * gs.s0 + -6.636063135e-02f; gs.p1 = gs.p1 * gs.s1 + -6.636063135e-02f;
-      asm volatile("" : "+v"(gs.p0), "+v"(gs.p1));
-    } else if (part == 4) {
-      gs.p0 = gs.p0 * gs.s0 + 3.989269649e-01f;  gs.p1 = gs.p1 * gs.s1 + 3.989269649e-01f;
-      gs.p0 = __builtin_amdgcn_fmed3f(gs.x0 * gs.p0 + 0.5f, 0.0f, 1.0f);
-      gs.p1 = __builtin_amdgcn_fmed3f(gs.x1 * gs.p1 + 0.5f, 0.0f, 1.0f);
-      asm volatile("" : "+v"(gs.p0), "+v"(gs.p1));
-    } else {
-      const int j0 = 4 * ((pair >> 1) & 1) + 2 * (pair & 1);
-      dst[j0] = (__bf16)(gs.x0 * gs.p0);
-      dst[j0 + 1] = (__bf16)(gs.x1 * gs.p1);
-      asm volatile("" : "+v"(dst));
-    }
-  };
-
-  // One chunk iteration: GEMM1 of chunk j1 into hn_next, then (unless first) GEMM2 of chunk j1 - 1
-  // from hb. Fragment i < NT is W1 k-block i, fragment NT + 2 T + kk is W2 tile T, k-block kk.
-  // A wave alone on its SIMD must never drain its LDS queue: the fragment reads run LOOK ahead of
-  // their MFMAs and every MFMA waits with an exact count. The compiler only places
-  // wait-for-everything on LDS reads here, so the steady-state path issues its reads and waits as
-  // inline asm (ASM_READS); the one-off first step keeps compiler-managed loads.
-  constexpr int LOOK = 8;
-  auto chunk_step = [&](int j1, auto first_tag) {
-    constexpr bool first = decltype(first_tag)::value;
-    constexpr bool ASM_READS = !first;
-    unsigned W1b = lds0 + ((2 * j1) % RING) * UNIT;
-    unsigned W2b = lds0 + ((2 * j1 + RING - 1) % RING) * UNIT;
-    unsigned bb1 = ldsb + 128 * j1;
-    asm volatile("" : "+v"(W1b), "+v"(W2b), "+v"(bb1));
-    constexpr int nf = first ? NT : NF;
-    bf16x8 wf[NF];
-    auto read_frag = [&](int i) {
-      if (ASM_READS) {
-        if (i < NT) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[i]) : "v"(W1b), "i"(i * 1024));
-        else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[i]) : "v"(W2b), "i"((i - NT) * 1024));
-      } else {
-        wf[i] = *(lds_frag)(size_t)(i < NT ? W1b + i * 1024 : W2b + (i - NT) * 1024);
-      }
-    };
-    // bias first (oldest in the queue), then the first LOOK fragments
-    f32x4 bq[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (ASM_READS) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[q]) : "v"(bb1), "i"(32 * q));
-      else bq[q] = *(lds_f4)(size_t)(bb1 + 32 * q);
-    }
-#pragma unroll
-    for (int i = 0; i < LOOK; ++i) read_frag(i);
-    if (ASM_READS) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]) : "i"(LOOK));
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      hn_next[4 * q + 0] = bq[q][0]; hn_next[4 * q + 1] = bq[q][1]; hn_next[4 * q + 2] = bq[q][2]; hn_next[4 * q + 3] = bq[q][3];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < NF; ++i) {
-      if (i < nf) {
-        if (i + LOOK < nf) read_frag(i + LOOK);
-        // reads younger than fragment i that may stay in flight
-        if (ASM_READS) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(wf[i]) : "i"(i + LOOK < nf ? LOOK : nf - 1 - i));
-        if (i < NT) {
-          hn_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xln[i], hn_next, 0, 0, 0);
-        } else {
-          const int T = (i - NT) >> 1, kk = (i - NT) & 1;
-          acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], hb[kk], acc[T], 0, 0, 0);
-        }
-      }
-      {
-        if (i < NT) {
-          // second half of GELU(hn_cur) -> hb[1], beside GEMM1 (skipped before the first chunk)
-          if (!first) {
-#pragma unroll
-            for (int g = 24 + i * 24 / NT; g < 24 + (i + 1) * 24 / NT; ++g) gelu_part(g, hn_cur, hb[1]);
-          }
-        } else {
-          // first half of GELU(hn_next) -> hb0_next, beside GEMM2 (or alone before the first chunk)
-#pragma unroll
-          for (int g = (i - NT) * 24 / NT; g < (i - NT + 1) * 24 / NT; ++g) gelu_part(g, hn_next, hb0_next);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);     // nothing moves between fragment steps
-    }
-    hn_cur = hn_next;
-    hb[0] = hb0_next;
-    asm volatile("" : "+v"(hb[0]), "+v"(hb[1]));
-  };
-
-  // units 0, 1, 2 landed (3 and 4 may still be in flight), bias table written
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_UNIT) : "memory");
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  hb[1] = xln[0];                    // defined value; overwritten before its first real use
-  chunk_step(0, std::true_type{});
-
-  for (int j = 0; j < nch; ++j) {
-    // units 2 j + 5 and 2 j + 6 go where units 2 j - 1 and 2 j were read during iteration j - 1
-    const int u5 = 2 * j + 5;
-    if (u5 < nunits) issue_unit(u5);
-    if (u5 + 1 < nunits) issue_unit(u5 + 1);
-    // GEMM1 of chunk j + 1 (past the end: a stale unit and zero biases, result unused), GEMM2 of chunk j
-    chunk_step(j + 1, std::false_type{});
-    // units 2 j + 3 and 2 j + 4 (issued one iteration ago) must have landed for every wave before
-    // the next iteration reads them; what this iteration issued stays in flight
-    if (u5 + 1 < nunits) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_UNIT) : "memory");
-    else if (u5 < nunits) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_UNIT) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-
-  // ---- epilogue: + b2, store the new residual rows
-  if (m < p.M) {
-    float* o = p.out + (size_t)m * D + 4 * h;
-#pragma unroll
-    for (int T = 0; T < NT32; ++T)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 b = *(const f32x4*)(p.b2 + 32 * T + 8 * q + 4 * h);
-        f32x4 v;
-        v[0] = acc[T][4 * q + 0] + b[0]; v[1] = acc[T][4 * q + 1] + b[1];
-        v[2] = acc[T][4 * q + 2] + b[2]; v[3] = acc[T][4 * q + 3] + b[3];
-        *(f32x4*)(o + 32 * T + 8 * q) = v;
-      }
-  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  stagger_start(p.stagger_blocks, p.stagger_units);
+  f32x16 acc[NT / 2];
+  load_rows(acc, p.x + (size_t)(m < p.M ? m : p.M - 1) * D + 4 * (lane >> 5));
+  ffn_phase<NT>(p.ph, smem, acc);
+  if (m < p.M) store_rows(acc, p.out + (size_t)m * D + 4 * (lane >> 5));
 }
 
 // Packs W1 (LayerNorm gamma already folded, bf16 [F, d]) and W2 (bf16 [d, F]) into the fragment
@@ -334,7 +106,7 @@ extern "C" int bd_ffn_pack_weights(const void* w1, const void* w2, void* out, in
 
 template <int NT>
 static int launch_ffn(const FfnArgs& a, hipStream_t stream) {
-  const size_t lds = 6 * (size_t)NT * 1024 + ((size_t)a.F + 32) * 4;
+  const size_t lds = ffn_phase_lds(NT, a.ph.F);
   hipFuncSetAttribute((const void*)ffn_fused_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((ffn_fused_kernel<NT>), dim3((a.M + 127) / 128), dim3(256), lds, stream, a);
   return bd_check_launch("bd_ffn_fused");
@@ -346,7 +118,7 @@ extern "C" int bd_ffn_fused(const float* x, float* out, const void* wpack, const
   BD_REQUIRE(x && out && wpack && b1 && b2, "bd_ffn_fused: null pointer");
   BD_REQUIRE(M > 0, "bd_ffn_fused: M=%d", M);
   BD_REQUIRE(bd_ffn_fused_supported(d, F), "bd_ffn_fused: unsupported d=%d F=%d", d, F);
-  FfnArgs a{x, out, (const unsigned char*)wpack, b1, b2, M, F, eps, 0, 0};
+  FfnArgs a{x, out, FfnPhase{(const unsigned char*)wpack, b1, b2, F, eps}, M, 0, 0};
   {
     static int ncu = 0;
     if (!ncu) {

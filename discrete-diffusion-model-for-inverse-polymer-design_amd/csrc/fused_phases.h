@@ -1,0 +1,571 @@
+// Device-side building blocks of the fused inference kernels (ffn_fused.hip, attn_block.hip,
+// backbone_mega.hip): the feed-forward phase and the attention phase of a transformer layer, each
+// working on residual rows held in registers (see those files for the design notes).
+#pragma once
+#include "bd_common.h"
+#include <type_traits>
+
+namespace bdf {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
+typedef __attribute__((address_space(3))) bf16x8* lds_frag_w;
+typedef const __attribute__((address_space(3))) f32x4* lds_f4;
+typedef const __attribute__((address_space(3))) float* lds_f1;
+
+struct Gelu2 { float x0, x1, s0, s1, p0, p1; };
+
+// bytes of LDS the phases need
+__host__ __device__ constexpr size_t ffn_phase_lds(int NT, int F) { return 6 * (size_t)NT * 1024 + ((size_t)F + 32) * 4; }
+__host__ __device__ constexpr size_t attn_phase_lds(int NT, int DH) {
+  return 3 * (size_t)NT * 1024 + 2 * (size_t)128 * DH * 2 + (size_t)NT * 16 * 4 + 128 * 4;
+}
+
+// Loads / stores of the wave's 32 rows in accumulator layout: acc[T][4 q + e] = row[32 T + 8 q + 4 h + e]
+template <int NT32>
+__device__ __forceinline__ void load_rows(f32x16 (&acc)[NT32], const float* xrow) {
+#pragma unroll
+  for (int T = 0; T < NT32; ++T)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *(const f32x4*)(xrow + 32 * T + 8 * q);
+      acc[T][4 * q + 0] = v[0]; acc[T][4 * q + 1] = v[1]; acc[T][4 * q + 2] = v[2]; acc[T][4 * q + 3] = v[3];
+    }
+  // the rows live in accumulation registers from here on (without this hint the compiler keeps
+  // all of them in ordinary VGPRs through the LayerNorm and spills about a hundred)
+#pragma unroll
+  for (int T = 0; T < NT32; ++T) asm volatile("" : "+a"(acc[T]));
+}
+template <int NT32>
+__device__ __forceinline__ void store_rows(const f32x16 (&acc)[NT32], float* orow) {
+#pragma unroll
+  for (int T = 0; T < NT32; ++T)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v;
+      v[0] = acc[T][4 * q + 0]; v[1] = acc[T][4 * q + 1]; v[2] = acc[T][4 * q + 2]; v[3] = acc[T][4 * q + 3];
+      *(f32x4*)(orow + 32 * T + 8 * q) = v;
+    }
+}
+// phase-shifted start of the first workgroup of every CU: all workgroups take the same time, so
+// without this every CU would load its rows, compute and store in lockstep, and the memory system
+// would alternate between overload and idleness
+__device__ __forceinline__ void stagger_start(int stagger_blocks, int stagger_units) {
+  if ((int)blockIdx.x < stagger_blocks) {
+    const int phase = (blockIdx.x >> 3) & 15;
+    for (int k = 0; k < phase * stagger_units; ++k) __builtin_amdgcn_s_sleep(32);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Feed-forward phase: acc (in) = the wave's 32 residual rows, acc (out) = rows + W2 GELU(W1 LN(rows)
+// + b1) + b2. smem: 6 units + (F + 32) floats. All four waves of the workgroup call it together;
+// nobody may still be using smem when they enter.
+struct FfnPhase {
+  const unsigned char* wpack;   // packed weight stream (bd_ffn_pack_weights)
+  const float* b1;              // [F] first bias with LayerNorm beta folded in
+  const float* b2;              // [d]
+  int F;
+  float eps;
+};
+
+template <int NT>
+__device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem, f32x16 (&acc)[NT / 2]) {
+  constexpr int D = NT * 16;
+  constexpr int NT32 = NT / 2;                // 32-feature tiles of the residual row
+  constexpr int UNIT = NT * 1024;             // unit 2 j = W1 of chunk j, unit 2 j + 1 = W2 of chunk j
+  constexpr int RING = 6;
+  constexpr int PER_UNIT = NT / 4;
+  constexpr int NF = 2 * NT;                  // fragments (= MFMAs) per chunk
+  constexpr int FB = 8;                       // fragment read batch
+  static_assert(NT % FB == 0, "fragment batches must tile both GEMMs");
+  float* const sb1 = (float*)(smem + RING * UNIT);     // F + 32 floats
+  typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
+  typedef const __attribute__((address_space(3))) f32x4* lds_f4;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: LDS-DMA targets stay scalar
+  const int h = lane >> 5;
+  const int nch = p.F >> 5;
+  const int nunits = 2 * nch;
+
+  auto issue_unit = [&](int u) {
+    const unsigned char* src = p.wpack + (size_t)u * UNIT + lane * 16;
+    unsigned char* dst = smem + (u % RING) * UNIT;
+#pragma unroll
+    for (int i = 0; i < PER_UNIT; ++i) {
+      const int f = wave + 4 * i;
+      __builtin_amdgcn_global_load_lds((glb_void*)(src + f * 1024), (lds_void*)(dst + f * 1024), 16, 0, 0);
+    }
+  };
+
+#pragma unroll
+  for (int u = 0; u < 5; ++u) issue_unit(u);            // F >= 96: the first five units exist
+  for (int i = tid; i < p.F + 32; i += 256) sb1[i] = i < p.F ? p.b1[i] : 0.f;
+
+  // ---- LayerNorm -> bf16 B operands (gamma / beta are folded into W1 and b1)
+  bf16x8 xln[NT];
+  {
+    float s = 0.f;
+#pragma unroll
+    for (int T = 0; T < NT32; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[T][r];
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int T = 0; T < NT32; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const float dv = acc[T][r] - mean; q += dv * dv; }
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = rsqrtf(q * (1.0f / D) + p.eps);
+#pragma unroll
+    for (int kb = 0; kb < NT; ++kb) {
+      bf16x8 f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = (__bf16)((acc[kb >> 1][8 * (kb & 1) + e] - mean) * rstd);
+      xln[kb] = f;
+    }
+  }
+
+  const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem + lane * 16;
+  const unsigned ldsb = (unsigned)(size_t)(lds_void*)sb1 + 16 * h;
+
+  f32x16 hn_cur, hn_next;      // GEMM1 results of chunk j and j + 1 (rows = hidden units of the chunk)
+  bf16x8 hb[2], hb0_next;      // GELU(hn_cur) as the two B operands of GEMM2; first half of the next
+  Gelu2 gs;
+
+  // GELU part g (0..47): pair g / 6 = registers 2 pair, 2 pair + 1 of the source tile, in six parts
+  auto gelu_part = [&](int g, const f32x16& src, bf16x8& dst) {
+    const int pair = g / 6, part = g % 6;
+    if (part == 0) {
+      gs.x0 = src[2 * pair]; gs.x1 = src[2 * pair + 1];
+      gs.s0 = fminf(gs.x0 * gs.x0, 16.0f); gs.s1 = fminf(gs.x1 * gs.x1, 16.0f);
+      asm volatile("" : "+v"(gs.s0), "+v"(gs.s1));
+    } else if (part == 1) {
+      gs.p0 = gs.s0 * -1.903182666e-09f + 1.410586241e-07f; gs.p1 = gs.s1 * -1.903182666e-09f + 1.410586241e-07f;
+      gs.p0 = gs.p0 * gs.s0 + -4.565313249e-06f;            gs.p1 = gs.p1 * gs.s1 + -4.565313249e-06f;
+      asm volatile("" : "+v"(gs.p0), "+v"(gs.p1));
+    } else if (part == 2) {
+      gs.p0 = gs.p0 * gs.s0 + 8.634553992e-05f;  gs.p1 = gs.p1 * gs.s1 + 8.634553992e-05f;
+      gs.p0 = gs.p0 * gs.s0 + -1.085383136e-03f; gs.p1 = gs.p1 * gs.s1 + -1.085383136e-03f;
+      asm volatile("" : "+v"(gs.p0), "+v"(gs.p1));
+    } else if (part == 3) {
+      gs.p0 = gs.p0 * gs.s0 + 9.789848745e-03f;  gs.p1 = gs.p1 * gs.s1 + 9.789848745e-03f;
+      gs.p0 = gs.p0 * gs.s0 + -6.636063135e-02f; gs.p1 = gs.p1 * gs.s1 + -6.636063135e-02f;
+      asm volatile("" : "+v"(gs.p0), "+v"(gs.p1));
+    } else if (part == 4) {
+      gs.p0 = gs.p0 * gs.s0 + 3.989269649e-01f;  gs.p1 = gs.p1 * gs.s1 + 3.989269649e-01f;
+      gs.p0 = __builtin_amdgcn_fmed3f(gs.x0 * gs.p0 + 0.5f, 0.0f, 1.0f);
+      gs.p1 = __builtin_amdgcn_fmed3f(gs.x1 * gs.p1 + 0.5f, 0.0f, 1.0f);
+      asm volatile("" : "+v"(gs.p0), "+v"(gs.p1));
+    } else {
+      const int j0 = 4 * ((pair >> 1) & 1) + 2 * (pair & 1);
+      dst[j0] = (__bf16)(gs.x0 * gs.p0);
+      dst[j0 + 1] = (__bf16)(gs.x1 * gs.p1);
+      asm volatile("" : "+v"(dst));
+    }
+  };
+
+  // One chunk iteration: GEMM1 of chunk j1 into hn_next, then (unless first) GEMM2 of chunk j1 - 1
+  // from hb. Fragment i < NT is W1 k-block i, fragment NT + 2 T + kk is W2 tile T, k-block kk.
+  // A wave alone on its SIMD must never drain its LDS queue: the fragment reads run LOOK ahead of
+  // their MFMAs and every MFMA waits with an exact count. The compiler only places
+  // wait-for-everything on LDS reads here, so the steady-state path issues its reads and waits as
+  // inline asm (ASM_READS); the one-off first step keeps compiler-managed loads.
+  constexpr int LOOK = 8;
+  auto chunk_step = [&](int j1, auto first_tag) {
+    constexpr bool first = decltype(first_tag)::value;
+    constexpr bool ASM_READS = !first;
+    unsigned W1b = lds0 + ((2 * j1) % RING) * UNIT;
+    unsigned W2b = lds0 + ((2 * j1 + RING - 1) % RING) * UNIT;
+    unsigned bb1 = ldsb + 128 * j1;
+    asm volatile("" : "+v"(W1b), "+v"(W2b), "+v"(bb1));
+    constexpr int nf = first ? NT : NF;
+    bf16x8 wf[NF];
+    auto read_frag = [&](int i) {
+      if (ASM_READS) {
+        if (i < NT) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[i]) : "v"(W1b), "i"(i * 1024));
+        else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[i]) : "v"(W2b), "i"((i - NT) * 1024));
+      } else {
+        wf[i] = *(lds_frag)(size_t)(i < NT ? W1b + i * 1024 : W2b + (i - NT) * 1024);
+      }
+    };
+    // bias first (oldest in the queue), then the first LOOK fragments
+    f32x4 bq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (ASM_READS) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[q]) : "v"(bb1), "i"(32 * q));
+      else bq[q] = *(lds_f4)(size_t)(bb1 + 32 * q);
+    }
+#pragma unroll
+    for (int i = 0; i < LOOK; ++i) read_frag(i);
+    if (ASM_READS) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]) : "i"(LOOK));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      hn_next[4 * q + 0] = bq[q][0]; hn_next[4 * q + 1] = bq[q][1]; hn_next[4 * q + 2] = bq[q][2]; hn_next[4 * q + 3] = bq[q][3];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      if (i < nf) {
+        if (i + LOOK < nf) read_frag(i + LOOK);
+        // reads younger than fragment i that may stay in flight
+        if (ASM_READS) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(wf[i]) : "i"(i + LOOK < nf ? LOOK : nf - 1 - i));
+        if (i < NT) {
+          hn_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xln[i], hn_next, 0, 0, 0);
+        } else {
+          const int T = (i - NT) >> 1, kk = (i - NT) & 1;
+          acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], hb[kk], acc[T], 0, 0, 0);
+        }
+      }
+      {
+        if (i < NT) {
+          // second half of GELU(hn_cur) -> hb[1], beside GEMM1 (skipped before the first chunk)
+          if (!first) {
+#pragma unroll
+            for (int g = 24 + i * 24 / NT; g < 24 + (i + 1) * 24 / NT; ++g) gelu_part(g, hn_cur, hb[1]);
+          }
+        } else {
+          // first half of GELU(hn_next) -> hb0_next, beside GEMM2 (or alone before the first chunk)
+#pragma unroll
+          for (int g = (i - NT) * 24 / NT; g < (i - NT + 1) * 24 / NT; ++g) gelu_part(g, hn_next, hb0_next);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);     // nothing moves between fragment steps
+    }
+    hn_cur = hn_next;
+    hb[0] = hb0_next;
+    asm volatile("" : "+v"(hb[0]), "+v"(hb[1]));
+  };
+
+  // units 0, 1, 2 landed (3 and 4 may still be in flight), bias table written
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_UNIT) : "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  hb[1] = xln[0];                    // defined value; overwritten before its first real use
+  chunk_step(0, std::true_type{});
+
+  for (int j = 0; j < nch; ++j) {
+    // units 2 j + 5 and 2 j + 6 go where units 2 j - 1 and 2 j were read during iteration j - 1
+    const int u5 = 2 * j + 5;
+    if (u5 < nunits) issue_unit(u5);
+    if (u5 + 1 < nunits) issue_unit(u5 + 1);
+    // GEMM1 of chunk j + 1 (past the end: a stale unit and zero biases, result unused), GEMM2 of chunk j
+    chunk_step(j + 1, std::false_type{});
+    // units 2 j + 3 and 2 j + 4 (issued one iteration ago) must have landed for every wave before
+    // the next iteration reads them; what this iteration issued stays in flight
+    if (u5 + 1 < nunits) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_UNIT) : "memory");
+    else if (u5 < nunits) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_UNIT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // + b2
+#pragma unroll
+  for (int T = 0; T < NT32; ++T)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b = *(const f32x4*)(p.b2 + 32 * T + 8 * q + 4 * h);
+      acc[T][4 * q + 0] += b[0]; acc[T][4 * q + 1] += b[1]; acc[T][4 * q + 2] += b[2]; acc[T][4 * q + 3] += b[3];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Attention phase for one sequence: acc (in) = the wave's 32 residual rows (token 32 wave + c of the
+// sequence), acc (out) = rows + Wo MHA(LN(rows)) + bias. The rows must also be in memory at xrow
+// (this lane's row pointer, + 4 h floats): they are re-read for the residual add at the end.
+// smem: 3 units + K and V fragments (2 x 256 dh bytes... 128 keys) + d + 128 floats.
+struct AttnPhase {
+  const unsigned char* wpack;   // packed weight stream (bd_attn_pack_weights)
+  const float* bq;              // [d]: q bias with LayerNorm beta folded, scaled like the q rows
+  const float* bo;              // [d] output bias
+  const float* bo_fold;         // [d] output bias + Wo * (v bias with LayerNorm beta folded)
+  const unsigned char* keymask; // this SEQUENCE's byte mask [L] (non-zero = visible) or null
+  int L;
+  float eps;
+};
+
+template <int NT, int DH>
+__device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* smem, f32x16 (&acc)[NT / 2], const float* xrow) {
+  constexpr int D = NT * 16;
+  constexpr int NT32 = NT / 2;
+  constexpr int H = D / DH;
+  constexpr int DT = DH / 32;                 // 32-row tiles of a head's q / k / v
+  constexpr int KBO = DH / 16;                // 16-wide k-blocks of a head
+  constexpr int UNIT = NT * 1024;
+  constexpr int RING = 3;
+  constexpr int PER_UNIT = NT / 4;
+  constexpr int QKV_UNITS = 3 * H * DT;
+  constexpr int NUNITS = QKV_UNITS + NT32;
+  constexpr int KV_BYTES = 128 * DH * 2;
+  constexpr int LOOK = NT >= 16 ? 8 : 4;      // fragment reads in flight
+  constexpr int MID = NT / 2;                 // MFMA index of a unit's barrier
+  static_assert(MID <= NT - LOOK, "the barrier must precede the first read of the next unit");
+  static_assert(NT % 4 == 0 && DH % 32 == 0 && D % DH == 0, "unsupported shape");
+  unsigned char* const sK = smem + RING * UNIT;
+  unsigned char* const sV = sK + KV_BYTES;
+  float* const sbias = (float*)(sV + KV_BYTES);        // d floats (q bias)
+  float* const smask = sbias + D;                  // 128 floats: 0 (visible) or -1e30
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5;
+  auto issue_unit = [&](int u) {
+    const unsigned char* src = p.wpack + (size_t)u * UNIT + lane * 16;
+    unsigned char* dst = smem + (u % RING) * UNIT;
+#pragma unroll
+    for (int i = 0; i < PER_UNIT; ++i) {
+      const int f = wave + 4 * i;
+      __builtin_amdgcn_global_load_lds((glb_void*)(src + f * 1024), (lds_void*)(dst + f * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- LayerNorm of the wave's 32 rows -> bf16 operands xln[kb] (row / column = token c,
+  //      k = feature 32 (kb / 2) + 8 (2 (kb % 2) + e / 4) + 4 h + e % 4)
+  bf16x8 xln[NT];
+  {
+    issue_unit(0);
+    issue_unit(1);
+    for (int i = tid; i < D; i += 256) sbias[i] = p.bq[i];
+    if (tid < 128) {
+      const bool vis = tid < p.L && (p.keymask == nullptr || p.keymask[tid] != 0);
+      smask[tid] = vis ? 0.f : -1e30f;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int T = 0; T < NT32; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[T][r];
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int T = 0; T < NT32; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const float dv = acc[T][r] - mean; q += dv * dv; }
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = rsqrtf(q * (1.0f / D) + p.eps);
+#pragma unroll
+    for (int kb = 0; kb < NT; ++kb) {
+      bf16x8 f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = (__bf16)((acc[kb >> 1][8 * (kb & 1) + e] - mean) * rstd);
+      xln[kb] = f;
+    }
+  }
+
+  const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem + lane * 16;
+  const unsigned ldsK = (unsigned)(size_t)(lds_void*)sK + lane * 16;
+  const unsigned ldsV = (unsigned)(size_t)(lds_void*)sV + lane * 16;
+  const unsigned ldsB = (unsigned)(size_t)(lds_void*)sbias;
+  const unsigned ldsM = (unsigned)(size_t)(lds_void*)smask + 16 * h;
+
+  // The weight stream is consumed as ONE continuous sequence of fragments. One unit = NT fragments
+  // -> NT MFMAs on one 32x32 accumulator; fragment i of a unit lives in register wf[i], and its LDS
+  // read is issued LOOK MFMAs earlier - across unit boundaries - with an exact wait count before
+  // each MFMA (inline asm: the compiler would wait for all outstanding reads each time, and a wave
+  // alone on its SIMD must not drain its LDS queue).
+  // Ring protocol, one barrier per unit, in its MIDDLE: when every wave has passed the middle of
+  // unit u, (a) every wave's LDS-DMA pieces of unit u + 1 have landed (each waits for its own
+  // before the barrier), so reading u + 1 may start during the tail of u, and (b) nobody reads
+  // unit u - 1 any more, so unit u + 2 is issued into that slot.
+  bf16x8 wf[NT];
+  auto mid_sync = [&](int u) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (u + 2 < NUNITS) issue_unit(u + 2);
+  };
+  // WEIGHT_IS_A: tile = W_frag * op (rows = weight rows), else tile = op * W_frag (rows = tokens).
+  auto run_unit = [&](int u, auto weight_is_a, auto last_unit, f32x16 t, const bf16x8 (&op)[NT]) -> f32x16 {
+    constexpr bool WEIGHT_IS_A = decltype(weight_is_a)::value;
+    constexpr bool LAST = decltype(last_unit)::value;
+    unsigned bc = lds0 + (u % RING) * UNIT, bn = lds0 + ((u + 1) % RING) * UNIT;
+    asm volatile("" : "+v"(bc), "+v"(bn));
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      if (i == MID) mid_sync(u);
+      const int j = i + LOOK;
+      if (j < NT) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[j]) : "v"(bc), "i"(j * 1024));
+      else if (!LAST) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[j - NT]) : "v"(bn), "i"((j - NT) * 1024));
+      // reads younger than fragment i that may stay in flight
+      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(wf[i]) : "i"((j < NT || !LAST) ? LOOK : NT - 1 - i));
+      if (WEIGHT_IS_A) t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], op[i], t, 0, 0, 0);
+      else t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[i], wf[i], t, 0, 0, 0);
+    }
+    return t;
+  };
+  // accumulator initialised with per-ROW values table[8 q + 4 h + e] (rows of a D tile)
+  auto rows_init = [&](unsigned addr) -> f32x16 {
+    f32x16 t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b = *(lds_f4)(size_t)(addr + 32 * q);
+      t[4 * q + 0] = b[0]; t[4 * q + 1] = b[1]; t[4 * q + 2] = b[2]; t[4 * q + 3] = b[3];
+    }
+    return t;
+  };
+  auto pack_half = [&](const f32x16& t, int kk) -> bf16x8 {
+    bf16x8 f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (__bf16)t[8 * kk + e];
+    return f;
+  };
+  f32x16 zero16;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+
+  // units 0 and 1 and the tables are staged; start the fragment stream
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  {
+    unsigned b0 = lds0;
+    asm volatile("" : "+v"(b0));
+#pragma unroll
+    for (int i = 0; i < LOOK; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[i]) : "v"(b0), "i"(i * 1024));
+  }
+
+  bf16x8 oall[NT];              // attention output of all heads as B operands of the Wo product
+#pragma unroll
+  for (int i = 0; i < NT; ++i) oall[i] = xln[0];   // defined values; every entry is overwritten
+  bool dead = false;            // every key of the sequence masked (same for all queries and heads)
+
+  int u = 0;
+#pragma nounroll
+  for (int hd = 0; hd < H; ++hd) {
+    // q bias rows of this head's tiles (the k bias shifts all scores of a query equally and drops
+    // out of the softmax; the v bias is folded into the output bias by the host)
+    f32x16 qinit[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) qinit[dt] = rows_init(ldsB + (hd * DH + 32 * dt + 4 * h) * 4);
+    // ---- Q^T tiles -> B operands of the score product
+    bf16x8 qb[KBO];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const f32x16 t = run_unit(u, std::true_type{}, std::false_type{}, qinit[dt], xln);
+      qb[2 * dt] = pack_half(t, 0);
+      qb[2 * dt + 1] = pack_half(t, 1);
+      ++u;
+    }
+    // ---- K^T tiles: rounded halves are the A fragments (row = key) of S = K Q^T
+#pragma nounroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const f32x16 t = run_unit(u, std::true_type{}, std::false_type{}, zero16, xln);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        *(lds_frag_w)(size_t)(ldsK + ((wave * KBO + 2 * dt + kk) << 10)) = pack_half(t, kk);
+      ++u;
+    }
+    // ---- V tiles (rows = tokens): rounded halves are the A fragments (row = dh) of O^T = V^T P^T
+#pragma nounroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const f32x16 t = run_unit(u, std::false_type{}, std::false_type{}, zero16, xln);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        *(lds_frag_w)(size_t)(ldsV + ((dt * 8 + 2 * wave + kk) << 10)) = pack_half(t, kk);
+      ++u;
+    }
+    // K and V of this head are complete and visible to all waves
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- S = K Q^T (rows = keys, columns = this wave's queries), key padding as initial value
+    f32x16 s[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) s[kt] = rows_init(ldsM + 128 * kt);
+    {
+      bf16x8 kf[4 * KBO];
+#pragma unroll
+      for (int i = 0; i < LOOK; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[i]) : "v"(ldsK), "i"(i * 1024));
+#pragma unroll
+      for (int i = 0; i < 4 * KBO; ++i) {
+        if (i + LOOK < 4 * KBO)
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[i + LOOK]) : "v"(ldsK), "i"((i + LOOK) * 1024));
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(kf[i]) : "i"(i + LOOK < 4 * KBO ? LOOK : 4 * KBO - 1 - i));
+        s[i / KBO] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i], qb[i % KBO], s[i / KBO], 0, 0, 0);
+      }
+    }
+    // ---- softmax over the keys of each query column (half of them in the lane c + 32)
+    float m = s[0][0];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, s[kt][r]);
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    dead = m < -1e29f;                        // every key masked
+    float l = 0.f;
+    bf16x8 pb[8];                             // P as B operands: k-block 2 kt + kk = 16 keys
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float pv = __builtin_amdgcn_exp2f(s[kt][8 * kk + e] - m);
+          l += pv;
+          f[e] = (__bf16)pv;
+        }
+        pb[2 * kt + kk] = f;
+      }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = dead ? 0.f : __builtin_amdgcn_rcpf(l);
+
+    // ---- O^T = V^T P^T (rows = dh, columns = queries) -> B operands of the Wo product
+    bf16x8 onew[KBO];
+    {
+      bf16x8 vf[DT * 8];
+#pragma unroll
+      for (int i = 0; i < LOOK; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vf[i]) : "v"(ldsV), "i"(i * 1024));
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+          const int i = dt * 8 + kb;
+          if (i + LOOK < DT * 8)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vf[i + LOOK]) : "v"(ldsV), "i"((i + LOOK) * 1024));
+          asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(vf[i]) : "i"(i + LOOK < DT * 8 ? LOOK : DT * 8 - 1 - i));
+          o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i], pb[kb], o, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] *= inv;
+        onew[2 * dt] = pack_half(o, 0);
+        onew[2 * dt + 1] = pack_half(o, 1);
+      }
+    }
+    // heads land in order: shift the array down by one head and append
+#pragma unroll
+    for (int i = 0; i + KBO < NT; ++i) oall[i] = oall[i + KBO];
+#pragma unroll
+    for (int i = 0; i < KBO; ++i) oall[NT - KBO + i] = onew[i];
+  }
+
+  // ---- out = Wo O^T: one unit per 32-feature tile
+#pragma unroll
+  for (int T = 0; T < NT32; ++T) {
+    if (T + 1 < NT32) acc[T] = run_unit(u, std::true_type{}, std::false_type{}, zero16, oall);
+    else acc[T] = run_unit(u, std::true_type{}, std::true_type{}, zero16, oall);
+    ++u;
+  }
+
+  // ---- + residual (re-read) + bias
+#pragma unroll
+  for (int T = 0; T < NT32; ++T)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 xv = *(const f32x4*)(xrow + 32 * T + 8 * q);
+      const f32x4 b = *(const f32x4*)((dead ? p.bo : p.bo_fold) + 32 * T + 8 * q + 4 * h);
+      acc[T][4 * q + 0] = acc[T][4 * q + 0] + xv[0] + b[0]; acc[T][4 * q + 1] = acc[T][4 * q + 1] + xv[1] + b[1];
+      acc[T][4 * q + 2] = acc[T][4 * q + 2] + xv[2] + b[2]; acc[T][4 * q + 3] = acc[T][4 * q + 3] + xv[3] + b[3];
+    }
+}
+
+}  // namespace bdf
