@@ -177,7 +177,8 @@ def main():
     kinds = {0: "gemm_bf16_kernel (tiled GEMM: vocabulary head and unfused projections)",
              1: "gemm_panel_kernel (row-panel projection with fused LayerNorm)",
              2: "ffn_fused_kernel (LayerNorm + fc1 + GELU + fc2 + residual)",
-             3: "attn_block_kernel (LayerNorm + QKV + attention + out-proj + residual)"}
+             3: "attn_block_kernel (LayerNorm + QKV + attention + out-proj + residual)",
+             4: "backbone_mega_kernel (whole forward: embeddings, all layers' attention + feed-forward phases, final LayerNorm)"}
     prof = {}
     for kind in kinds:
         n_k, ms_k, fl_k = C.c_longlong(0), C.c_double(0.0), C.c_double(0.0)

@@ -2,6 +2,7 @@
 // kernel chain of one forward pass on the given stream.
 #include "bd_common.h"
 #include "bidiff.h"
+#include <stdlib.h>
 
 namespace {
 inline long long align256(long long x) { return (x + 255) & ~255ll; }
@@ -72,6 +73,18 @@ int forward_impl(const bd_backbone_desc* desc, const long long* ids, const long 
   const int d = c.d, F = c.ffn, Mi = (int)M;
   const int aw = c.attn_width > 0 ? c.attn_width : d;   // q / k / v row width (padded heads)
 
+  // Whole forward in one launch when the model fits the fused phases (one sequence per workgroup,
+  // residual rows in registers across all layers); BD_MEGA=0 in the environment keeps the
+  // per-layer kernels (for comparisons).
+  static const bool mega_enabled = []() { const char* e = getenv("BD_MEGA"); return !(e && e[0] == '0'); }();
+  if (mega_enabled && n_run == c.n_layers && resid_out == nullptr && (hidden_out != nullptr || logits_out != nullptr) &&
+      bd_backbone_mega_supported(desc, L)) {
+    void* hf = hidden_out ? hidden_out : h;
+    if ((rc = bd_backbone_mega(desc, ids, timesteps, keymask, B, L, x, hf, stream))) return rc;
+    if (logits_out != nullptr)
+      return bd_gemm_bf16(hf, c.w_out, nullptr, logits_out, Mi, c.vocab_pad, c.vocab, d, c.vocab, 3, stream);
+    return BD_OK;
+  }
   if ((rc = bd_embed(ids, timesteps, c.tok_emb, c.pos_emb, c.time_emb, x, B, L, d, stream))) return rc;
   // Fused kernels whenever the shapes allow: the whole attention block in one kernel per sequence
   // and the whole feed-forward block in one kernel per 128-token panel (nothing but the residual

@@ -1,0 +1,207 @@
+// Whole denoiser forward in ONE launch, one sequence (L <= 128) per workgroup:
+//   embeddings -> n_layers x [attention phase, feed-forward phase] -> final LayerNorm -> bf16 hidden.
+// Sequences never interact, so a workgroup carries its sequence through every layer without any
+// grid-wide synchronisation. The residual rows stay in registers from phase to phase (the
+// attention phase's output layout IS the feed-forward phase's input layout, and vice versa); once
+// per layer they are also written to a scratch row buffer because the attention phase re-reads
+// them for its residual add - 196 KB per workgroup that the same CU wrote a few tens of
+// microseconds earlier, served from L2 / Infinity Cache. HBM sees the ids, the weights and the
+// final hidden states; between layers nothing drains, no kernel boundary, no tail.
+#include "bd_common.h"
+#include "bd_prof.h"
+#include "bidiff.h"
+#include "fused_phases.h"
+
+namespace {
+
+using namespace bdf;
+
+constexpr int MEGA_MAX_LAYERS = 32;
+
+struct MegaLayer {
+  const unsigned char* attn_pack;
+  const float* bq;
+  const float* bo;
+  const float* bo_fold;
+  const unsigned char* ffn_pack;
+  const float* b1;
+  const float* b2;
+};
+
+struct MegaArgs {
+  const long long* ids;          // [B, L]
+  const long long* timesteps;    // [B]
+  const unsigned char* keymask;  // [B, L] or null
+  const float* tok_emb;
+  const float* pos_emb;
+  const float* time_emb;
+  const float* lnf_g;
+  const float* lnf_b;
+  float* xbuf;                   // [B * L, d] scratch rows
+  unsigned short* hidden;        // [B * L, d] bf16 final-norm output
+  int B, L, F, n_layers;
+  float eps;
+  int stagger_blocks, stagger_units;
+  MegaLayer layers[MEGA_MAX_LAYERS];
+};
+
+template <int NT, int DH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void backbone_mega_kernel(MegaArgs p) {
+  constexpr int D = NT * 16;
+  constexpr int NT32 = NT / 2;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, c = lane & 31;
+  const int seq = blockIdx.x, L = p.L;
+  const int tok = 32 * wave + c;
+  const bool valid = tok < L;
+  const int tokc = valid ? tok : L - 1;                 // lanes past the sequence shadow its last row
+  const size_t row = (size_t)seq * L + tokc;
+  float* const xrow = p.xbuf + row * D + 4 * h;
+  stagger_start(p.stagger_blocks, p.stagger_units);
+
+  // ---- embeddings: x = (token + position) + timestep, straight into accumulator layout
+  f32x16 acc[NT32];
+  {
+    const float* te = p.tok_emb + (size_t)p.ids[row] * D + 4 * h;
+    const float* pe = p.pos_emb + (size_t)tokc * D + 4 * h;
+    const float* me = p.time_emb + (size_t)p.timesteps[seq] * D + 4 * h;
+#pragma unroll
+    for (int T = 0; T < NT32; ++T)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 a = *(const f32x4*)(te + 32 * T + 8 * q);
+        const f32x4 b = *(const f32x4*)(pe + 32 * T + 8 * q);
+        const f32x4 m = *(const f32x4*)(me + 32 * T + 8 * q);
+        acc[T][4 * q + 0] = (a[0] + b[0]) + m[0]; acc[T][4 * q + 1] = (a[1] + b[1]) + m[1];
+        acc[T][4 * q + 2] = (a[2] + b[2]) + m[2]; acc[T][4 * q + 3] = (a[3] + b[3]) + m[3];
+      }
+#pragma unroll
+    for (int T = 0; T < NT32; ++T) asm volatile("" : "+a"(acc[T]));
+  }
+
+  AttnPhase ap;
+  ap.keymask = p.keymask ? p.keymask + (size_t)seq * L : nullptr;
+  ap.L = L;
+  ap.eps = p.eps;
+  FfnPhase fp;
+  fp.F = p.F;
+  fp.eps = p.eps;
+
+#pragma nounroll
+  for (int l = 0; l < p.n_layers; ++l) {
+    // the rows go to memory for the attention phase's residual re-read (same lane, same address)
+    if (valid) store_rows(acc, xrow);
+    const MegaLayer& lw = p.layers[l];
+    ap.wpack = lw.attn_pack; ap.bq = lw.bq; ap.bo = lw.bo; ap.bo_fold = lw.bo_fold;
+    fp.wpack = lw.ffn_pack; fp.b1 = lw.b1; fp.b2 = lw.b2;
+    // every wave has left the previous phase's LDS; no memory operation of this wave is pending
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    attn_phase<NT, DH>(ap, smem, acc, xrow);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    ffn_phase<NT>(fp, smem, acc);
+  }
+
+  // ---- final LayerNorm (affine) -> bf16 hidden rows
+  {
+    float s = 0.f;
+#pragma unroll
+    for (int T = 0; T < NT32; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[T][r];
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / D);
+    float q2 = 0.f;
+#pragma unroll
+    for (int T = 0; T < NT32; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const float dv = acc[T][r] - mean; q2 += dv * dv; }
+    q2 += __shfl_xor(q2, 32, 64);
+    const float rstd = rsqrtf(q2 * (1.0f / D) + p.eps);
+    if (valid) {
+      unsigned short* o = p.hidden + row * D + 4 * h;
+#pragma unroll
+      for (int T = 0; T < NT32; ++T)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 g = *(const f32x4*)(p.lnf_g + 32 * T + 8 * q + 4 * h);
+          const f32x4 b = *(const f32x4*)(p.lnf_b + 32 * T + 8 * q + 4 * h);
+          u32x2 w;
+          w[0] = bd_pack_bf16x2((acc[T][4 * q + 0] - mean) * rstd * g[0] + b[0], (acc[T][4 * q + 1] - mean) * rstd * g[1] + b[1]);
+          w[1] = bd_pack_bf16x2((acc[T][4 * q + 2] - mean) * rstd * g[2] + b[2], (acc[T][4 * q + 3] - mean) * rstd * g[3] + b[3]);
+          *(u32x2*)(o + 32 * T + 8 * q) = w;
+        }
+    }
+  }
+}
+
+template <int NT, int DH>
+int launch_mega(const MegaArgs& a, hipStream_t stream) {
+  const size_t la = attn_phase_lds(NT, DH), lf = ffn_phase_lds(NT, a.F);
+  const size_t lds = la > lf ? la : lf;
+  hipFuncSetAttribute((const void*)backbone_mega_kernel<NT, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((backbone_mega_kernel<NT, DH>), dim3(a.B), dim3(256), lds, stream, a);
+  return bd_check_launch("bd_backbone_mega");
+}
+
+}  // namespace
+
+extern "C" int bd_backbone_mega_supported(const bd_backbone_desc* c, int L) {
+  if (c == nullptr || c->n_layers < 1 || c->n_layers > MEGA_MAX_LAYERS) return 0;
+  if (c->attn_width != 0 && c->attn_width != c->d) return 0;
+  if (!bd_attn_block_supported(c->d, c->n_heads, L) || !bd_ffn_fused_supported(c->d, c->ffn)) return 0;
+  if (ffn_phase_lds(c->d / 16, c->ffn) > 160 * 1024) return 0;
+  for (int i = 0; i < c->n_layers; ++i) {
+    const bd_layer_weights& lw = c->layers[i];
+    if (!lw.attn_pack || !lw.b_q_attn || !lw.b_o_fold || !lw.b_o || !lw.ffn_pack || !lw.b_fc1_ln || !lw.b_fc2) return 0;
+  }
+  return 1;
+}
+
+extern "C" int bd_backbone_mega(const bd_backbone_desc* desc, const long long* ids, const long long* timesteps,
+                                const unsigned char* keymask, int B, int L, float* xbuf, void* hidden_out,
+                                void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BD_REQUIRE(desc && ids && timesteps && xbuf && hidden_out, "bd_backbone_mega: null operand");
+  BD_REQUIRE(B > 0, "bd_backbone_mega: B=%d", B);
+  BD_REQUIRE(bd_backbone_mega_supported(desc, L), "bd_backbone_mega: unsupported model shape or L=%d", L);
+  const bd_backbone_desc& c = *desc;
+  MegaArgs a{};
+  a.ids = ids; a.timesteps = timesteps; a.keymask = keymask;
+  a.tok_emb = c.tok_emb; a.pos_emb = c.pos_emb; a.time_emb = c.time_emb;
+  a.lnf_g = c.lnf_g; a.lnf_b = c.lnf_b;
+  a.xbuf = xbuf; a.hidden = (unsigned short*)hidden_out;
+  a.B = B; a.L = L; a.F = c.ffn; a.n_layers = c.n_layers; a.eps = c.ln_eps;
+  for (int i = 0; i < c.n_layers; ++i) {
+    const bd_layer_weights& lw = c.layers[i];
+    a.layers[i] = MegaLayer{(const unsigned char*)lw.attn_pack, lw.b_q_attn, lw.b_o, lw.b_o_fold,
+                            (const unsigned char*)lw.ffn_pack, lw.b_fc1_ln, lw.b_fc2};
+  }
+  {
+    static int ncu = 0;
+    if (!ncu) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+      else ncu = 256;
+    }
+    a.stagger_blocks = (B >= 4 * ncu) ? ncu : 0;
+    a.stagger_units = 3;
+  }
+  const int d = c.d, dh = d / c.n_heads;
+  void* tok = bd_prof_on() ? bd_prof_begin(stream) : nullptr;
+  int rc;
+  if (d == 384) rc = launch_mega<24, 128>(a, stream);
+  else if (d == 256 && dh == 128) rc = launch_mega<16, 128>(a, stream);
+  else if (d == 256) rc = launch_mega<16, 64>(a, stream);
+  else if (dh == 64) rc = launch_mega<8, 64>(a, stream);
+  else rc = launch_mega<8, 32>(a, stream);
+  // algorithmic work of the layers: projections, attention products, feed-forward
+  if (tok) bd_prof_end(tok, stream, (double)c.n_layers * 2.0 * (double)B * L * (4.0 * d * d + 2.0 * L * d + 2.0 * d * c.ffn),
+                       BD_PROF_MEGA);
+  return rc;
+}

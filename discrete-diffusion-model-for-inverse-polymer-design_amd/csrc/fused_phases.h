@@ -72,6 +72,9 @@ struct FfnPhase {
 
 template <int NT>
 __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem, f32x16 (&acc)[NT / 2]) {
+  // the rows live in accumulation registers (see load_rows)
+#pragma unroll
+  for (int T = 0; T < NT / 2; ++T) asm volatile("" : "+a"(acc[T]));
   constexpr int D = NT * 16;
   constexpr int NT32 = NT / 2;                // 32-feature tiles of the residual row
   constexpr int UNIT = NT * 1024;             // unit 2 j = W1 of chunk j, unit 2 j + 1 = W2 of chunk j

@@ -169,6 +169,15 @@ int bd_backbone_forward(const bd_backbone_desc* desc, const long long* ids,
                         void* workspace, long long workspace_bytes, void* hidden_out,
                         float* logits_out, void* stream);
 
+/* The same forward as ONE kernel launch, one sequence per workgroup, when bd_backbone_mega_supported
+ * (every layer carries the fused-kernel weight streams, L <= 128, n_layers <= 32): embeddings, all
+ * layers and the final LayerNorm; the residual rows stay in registers from phase to phase. xbuf
+ * [B*L, d] fp32 is scratch, hidden_out [B*L, d] bf16 the final-norm output. bd_backbone_forward
+ * takes this route by itself (environment BD_MEGA=0 turns it off). */
+int bd_backbone_mega_supported(const bd_backbone_desc* desc, int L);
+int bd_backbone_mega(const bd_backbone_desc* desc, const long long* ids, const long long* timesteps,
+                     const unsigned char* keymask, int B, int L, float* xbuf, void* hidden_out, void* stream);
+
 /* Embeddings + the first n_run blocks only; resid_out [B*L, d] fp32 receives the residual stream
  * (no final LayerNorm). Replaces get_hidden_states(layer_idx = n_run - 1 >= 0),
  * src/model/backbone.py:259-299. */
@@ -349,7 +358,7 @@ float bd_host_uniform_token(unsigned long long seed, uint32_t seq, uint32_t t, u
 int bd_prof_enable(int on);
 int bd_prof_read(long long* launches, double* total_ms, double* total_flops, int reset);
 /* Same, for one kernel family: 0 tiled GEMM, 1 row-panel GEMM, 2 fused feed-forward block,
- * 3 fused attention block; -1 = all families together. */
+ * 3 fused attention block, 4 whole-forward kernel; -1 = all families together. */
 int bd_prof_read_kind(int kind, long long* launches, double* total_ms, double* total_flops, int reset);
 
 #ifdef __cplusplus

@@ -114,6 +114,31 @@ def test_intermediate_hidden_states_match_oracle(gpu_device):
             bbg.get_hidden_states(ids.to(gpu_device), t.to(gpu_device), attn.to(gpu_device), layer_idx=3)
 
 
+def test_single_launch_forward_equals_per_layer_kernels(gpu_device):
+    """The one-kernel forward (rows in registers across all layers) and the per-layer fused kernels run
+    the same phases on the same operands: the final hidden states agree to bf16 rounding."""
+    from bidiff import _lib
+    import ctypes as C
+    cfg = dict(RI.SMALL_CFG, num_layers=3, dropout=0.0)
+    torch.manual_seed(2)
+    bb = DiffusionBackbone(**cfg).eval()
+    RI.perturb_state_dict(bb.state_dict(), 13)
+    ids, attn, t = (torch.from_numpy(x).to(gpu_device) for x in RI.backbone_inputs(cfg, 8, B=7, L=100))
+    bbg = bb.to(gpu_device)
+    with torch.no_grad():
+        assert _lib.lib().bd_backbone_mega_supported(C.byref(bbg.packed().desc), 100) == 1
+        one = bbg.get_hidden_states(ids, t, attn)                         # single launch + final norm inside
+        resid = bbg.get_hidden_states(ids, t, attn, layer_idx=2)          # per-layer kernels, residual stream
+        per_layer = torch.nn.functional.layer_norm(resid, (cfg["hidden_size"],), bbg.final_norm.weight,
+                                                   bbg.final_norm.bias, bbg.final_norm.eps)
+    valid = attn.bool()
+    a, b = one[valid], per_layer[valid]
+    assert torch.isfinite(a).all()
+    assert (a - b).abs().max().item() <= 2.0 ** -7 * b.abs().max().item()    # one bf16 ulp of the largest value
+    # not supported: longer sequences fall back to the per-layer path
+    assert _lib.lib().bd_backbone_mega_supported(C.byref(bbg.packed().desc), 129) == 0
+
+
 def test_cpu_tensors_fail_loudly():
     cfg, bb = tiny_model("tiny_h2")
     ids, attn, t = RI.backbone_inputs(cfg, 21)
