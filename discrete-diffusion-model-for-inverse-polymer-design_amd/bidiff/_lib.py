@@ -57,6 +57,11 @@ class BackboneDesc(C.Structure):
     ]
 
 
+class Dropout(C.Structure):
+    """bd_dropout: keep decisions are a function of (seed, step, site, row, column)."""
+    _fields_ = [("p", C.c_float), ("step", C.c_uint), ("seed", C.c_ulonglong)]
+
+
 class StepArgs(C.Structure):
     _fields_ = [
         ("ids", VP), ("fixed", VP), ("attn", VP), ("keymask", VP), ("has_eos", VP),
@@ -93,6 +98,14 @@ SIGNATURES = {
     "bd_version": (C.c_char_p, []),
     "bd_last_error": (C.c_char_p, []),
     "bd_device_available": (C.c_int, []),
+    "bd_dropout_f32": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, C.c_uint, VP]),
+    "bd_dropout_f32_to_bf16": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, C.c_uint, VP]),
+    "bd_embed_drop": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP, C.c_uint, VP]),
+    "bd_gemm_bf16_drop": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    VP, C.c_uint, VP]),
+    "bd_attention_fwd_drop": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, C.c_uint, VP]),
+    "bd_attention_bwd_drop": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP,
+                                        C.c_uint, VP]),
     "bd_embed": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP]),
     "bd_layernorm": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_float, VP]),
     "bd_gemm_bf16": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
@@ -132,6 +145,7 @@ SIGNATURES = {
     "bd_sample_fixup": (C.c_int, [C.POINTER(FixArgs), VP]),
     "bd_host_gumbel": (None, [VP, VP, C.c_longlong]),
     "bd_host_philox": (None, [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]),
+    "bd_host_dropout_factors": (C.c_int, [VP, C.c_uint, C.c_longlong, C.c_longlong, VP]),
     "bd_host_uniform_select": (C.c_float, [C.c_ulonglong, C.c_uint32, C.c_uint32, C.c_uint32]),
     "bd_host_uniform_token": (C.c_float, [C.c_ulonglong, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "bd_prof_enable": (C.c_int, [C.c_int]),

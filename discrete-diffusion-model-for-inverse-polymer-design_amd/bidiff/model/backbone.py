@@ -104,6 +104,11 @@ class DiffusionBackbone(nn.Module):
         self._init_weights()
         self._packed = _Packed()
         self._ws = None
+        # Training dropout: keep decisions are a function of (dropout_seed, forward-pass counter,
+        # site, element). dropout_seed None = drawn from torch's CPU generator at the first
+        # training forward (so torch.manual_seed fixes it) and offset by the process rank.
+        self.dropout_seed: Optional[int] = None
+        self._drop_step = 0
 
     # ------------------------------------------------------------------ init
     def _init_weights(self):
@@ -122,6 +127,22 @@ class DiffusionBackbone(nn.Module):
             elif isinstance(m, nn.LayerNorm):
                 nn.init.ones_(m.weight)
                 nn.init.zeros_(m.bias)
+
+    def _next_dropout(self):
+        """bd_dropout of the next training forward pass, or None when dropout is off (eval mode or
+        p == 0; reference: nn.Dropout and SDPA ``dropout_p if self.training``, backbone.py:30,65)."""
+        if not self.training or self.dropout <= 0.0:
+            return None
+        if not self.dropout < 1.0:
+            raise ValueError(f"dropout must be in [0, 1), got {self.dropout}")
+        if self.dropout_seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                seed = (seed + 0x9E3779B97F4A7C15 * torch.distributed.get_rank()) % (2 ** 64)
+            self.dropout_seed = seed
+        drop = _lib.Dropout(float(self.dropout), self._drop_step & 0xFFFFFFFF, int(self.dropout_seed) % (2 ** 64))
+        self._drop_step += 1
+        return drop
 
     # ------------------------------------------------------------------ packing
     def _pack_key(self):

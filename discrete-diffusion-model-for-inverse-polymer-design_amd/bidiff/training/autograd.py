@@ -4,8 +4,10 @@ kernels need, and backward passes that chain those kernels.
 ``backbone_forward_train`` is what ``DiffusionBackbone.forward`` runs when autograd is
 recording (reference call site: ``DiscreteMaskingDiffusion.forward``, diffusion.py:156, under
 ``BackboneTrainer._train_step``, trainer_backbone.py:434-439); ``masked_cross_entropy`` is
-``_compute_loss`` (diffusion.py:169-209). Dropout is not applied (the kernels implement the
-``dropout = 0`` network).
+``_compute_loss`` (diffusion.py:169-209). In training mode with ``dropout > 0`` the four dropout
+sites of the reference (embedding sum backbone.py:247, attention probabilities :65, GELU output :98,
+fc2 output :100) are applied inside the kernels from a counter-based decision stream that the
+backward kernels regenerate; no mask tensor exists.
 """
 import ctypes as C
 
@@ -23,9 +25,14 @@ def _ck(rc, what):
         _lib.check(rc, what)
 
 
-def _gemm(A, W, bias, out, M, n_pad, n_real, K, ldc, epi, aux_in=None, aux_out=None):
-    _ck(_lib.lib().bd_gemm_bf16_aux(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(aux_in),
-                                    _lib.ptr(aux_out), M, n_pad, n_real, K, ldc, epi, _s()), "bd_gemm_bf16")
+def _dp(drop):
+    return None if drop is None else C.byref(drop)
+
+
+def _gemm(A, W, bias, out, M, n_pad, n_real, K, ldc, epi, aux_in=None, aux_out=None, drop=None, site=0):
+    _ck(_lib.lib().bd_gemm_bf16_drop(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(aux_in),
+                                     _lib.ptr(aux_out), M, n_pad, n_real, K, ldc, epi, _dp(drop), site, _s()),
+        "bd_gemm_bf16")
 
 
 def _ln(x, g, b, out_bf16, stats, M, d, eps):
@@ -47,8 +54,12 @@ def _colsum(dY, out, M, N):
     _ck(_lib.lib().bd_colsum_bf16(_lib.ptr(dY), dY.stride(0), _lib.ptr(out), M, N, _s()), "bd_colsum_bf16")
 
 
-def _to_bf16(x, out):
-    _ck(_lib.lib().bd_cast_f32_to_bf16(_lib.ptr(x), _lib.ptr(out), x.numel(), _s()), "bd_cast_f32_to_bf16")
+def _to_bf16(x, out, drop=None, site=0):
+    if drop is None:
+        _ck(_lib.lib().bd_cast_f32_to_bf16(_lib.ptr(x), _lib.ptr(out), x.numel(), _s()), "bd_cast_f32_to_bf16")
+    else:
+        _ck(_lib.lib().bd_dropout_f32_to_bf16(_lib.ptr(x), _lib.ptr(out), x.shape[0], x.shape[1], _dp(drop), site,
+                                              _s()), "bd_dropout_f32_to_bf16")
 
 
 class _TrainWeights:
@@ -118,12 +129,13 @@ class _BackboneFn(torch.autograd.Function):
         eps = float(model.final_norm.eps)
         tw = _train_weights(model)
         aw = tw.aw
+        drop = model._next_dropout()          # None in eval mode or with dropout = 0
         x = torch.empty(M, d, device=dev)
-        _ck(lib.bd_embed(_lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(model.token_embedding.weight),
-                         _lib.ptr(model.position_embedding.weight), _lib.ptr(model.timestep_embedding.weight),
-                         _lib.ptr(x), B, L, d, _s()), "bd_embed")
+        _ck(lib.bd_embed_drop(_lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(model.token_embedding.weight),
+                              _lib.ptr(model.position_embedding.weight), _lib.ptr(model.timestep_embedding.weight),
+                              _lib.ptr(x), B, L, d, _dp(drop), 0, _s()), "bd_embed")
         saved = []
-        for blk, w in zip(model.layers, tw.layers):
+        for li, (blk, w) in enumerate(zip(model.layers, tw.layers)):
             s = {"x_in": x}
             s["st1"] = torch.empty(M, 2, device=dev)
             s["h1"] = torch.empty(M, d, dtype=bf, device=dev)
@@ -132,8 +144,8 @@ class _BackboneFn(torch.autograd.Function):
             _gemm(s["h1"], w["wqkv"], w["bqkv"], s["qkv"], M, 3 * aw, 3 * aw, d, 3 * aw, 0)
             s["att"] = torch.empty(M, aw, dtype=bf, device=dev)
             s["lse"] = torch.empty(B, H, L, device=dev)
-            _ck(lib.bd_attention_fwd(_lib.ptr(s["qkv"]), _lib.ptr(keymask), _lib.ptr(s["att"]), _lib.ptr(s["lse"]),
-                                     B, L, H, aw // H, _s()), "bd_attention_fwd")
+            _ck(lib.bd_attention_fwd_drop(_lib.ptr(s["qkv"]), _lib.ptr(keymask), _lib.ptr(s["att"]), _lib.ptr(s["lse"]),
+                                          B, L, H, aw // H, _dp(drop), 4 * li + 1, _s()), "bd_attention_fwd")
             x_mid = torch.empty(M, d, device=dev)
             _gemm(s["att"], w["wo"], blk.attn.out_proj.bias, x_mid, M, d, d, aw, d, 2, aux_in=x)
             s["x_mid"] = x_mid
@@ -142,9 +154,11 @@ class _BackboneFn(torch.autograd.Function):
             _ln(x_mid, blk.norm2.weight, blk.norm2.bias, s["h2"], s["st2"], M, d, eps)
             s["u"] = torch.empty(M, F, dtype=bf, device=dev)
             s["a"] = torch.empty(M, F, dtype=bf, device=dev)
-            _gemm(s["h2"], w["w1"], blk.ffn.fc1.bias, s["a"], M, F, F, d, F, 1, aux_out=s["u"])
+            _gemm(s["h2"], w["w1"], blk.ffn.fc1.bias, s["a"], M, F, F, d, F, 1, aux_out=s["u"], drop=drop,
+                  site=4 * li + 2)
             x_out = torch.empty(M, d, device=dev)
-            _gemm(s["a"], w["w2"], blk.ffn.fc2.bias, x_out, M, d, d, F, d, 2, aux_in=x_mid)
+            _gemm(s["a"], w["w2"], blk.ffn.fc2.bias, x_out, M, d, d, F, d, 2, aux_in=x_mid, drop=drop,
+                  site=4 * li + 3)
             saved.append(s)
             x = x_out
         stf = torch.empty(M, 2, device=dev)
@@ -152,7 +166,7 @@ class _BackboneFn(torch.autograd.Function):
         _ln(x, model.final_norm.weight, model.final_norm.bias, hf, stf, M, d, eps)
         logits = torch.empty(B, L, V, device=dev)
         _gemm(hf, tw.wout, None, logits, M, tw.vpad, V, d, V, 3)
-        ctx.model, ctx.saved, ctx.tw = model, saved, tw
+        ctx.model, ctx.saved, ctx.tw, ctx.drop = model, saved, tw, drop
         ctx.x_last, ctx.stf, ctx.hf = x, stf, hf
         ctx.ids, ctx.timesteps, ctx.keymask = ids, timesteps, keymask
         return logits
@@ -160,7 +174,7 @@ class _BackboneFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         lib = _lib.lib()
-        model, tw = ctx.model, ctx.tw
+        model, tw, drop = ctx.model, ctx.tw, ctx.drop
         ids, timesteps, keymask = ctx.ids, ctx.timesteps, ctx.keymask
         B, L = ids.shape
         M = B * L
@@ -207,13 +221,14 @@ class _BackboneFn(torch.autograd.Function):
         datt = torch.empty(M, aw, dtype=bf, device=dev)
         dqkv = torch.empty(M, 3 * aw, dtype=bf, device=dev)
         delta = torch.empty(B, H, L, device=dev)
-        for blk, w, s in zip(reversed(model.layers), reversed(tw.layers), reversed(ctx.saved)):
+        for li, blk, w, s in zip(reversed(range(len(model.layers))), reversed(model.layers), reversed(tw.layers),
+                                 reversed(ctx.saved)):
             a = blk.attn
-            # x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
-            _to_bf16(dx, dy)
+            # x_out = x_mid + drop(fc2(drop(gelu(fc1(LN2(x_mid))))))
+            _to_bf16(dx, dy, drop, 4 * li + 3)
             _wgrad(dy, s["a"], gbuf(blk.ffn.fc2.weight), M, d, F)
             _colsum(dy, gbuf(blk.ffn.fc2.bias), M, d)
-            _gemm(dy, w["w2T"], None, du, M, F, F, d, F, 4, aux_in=s["u"])
+            _gemm(dy, w["w2T"], None, du, M, F, F, d, F, 4, aux_in=s["u"], drop=drop, site=4 * li + 2)
             _wgrad(du, s["h2"], gbuf(blk.ffn.fc1.weight), M, F, d)
             _colsum(du, gbuf(blk.ffn.fc1.bias), M, F)
             _gemm(du, w["w1T"], None, dh_buf, M, d, d, F, d, 0)
@@ -228,9 +243,9 @@ class _BackboneFn(torch.autograd.Function):
                 gbuf(a.out_proj.weight).view(d, H, dh).add_(tmp.view(d, H, dhp)[:, :, :dh])
             _colsum(dy, gbuf(a.out_proj.bias), M, d)
             _gemm(dy, w["woT"], None, datt, M, aw, aw, d, aw, 0)
-            _ck(lib.bd_attention_bwd(_lib.ptr(s["qkv"]), _lib.ptr(keymask), _lib.ptr(s["att"]), _lib.ptr(datt),
-                                     _lib.ptr(s["lse"]), _lib.ptr(delta), _lib.ptr(dqkv), B, L, H, aw // H, _s()),
-                "bd_attention_bwd")
+            _ck(lib.bd_attention_bwd_drop(_lib.ptr(s["qkv"]), _lib.ptr(keymask), _lib.ptr(s["att"]), _lib.ptr(datt),
+                                          _lib.ptr(s["lse"]), _lib.ptr(delta), _lib.ptr(dqkv), B, L, H, aw // H,
+                                          _dp(drop), 4 * li + 1, _s()), "bd_attention_bwd")
             for i, proj in enumerate((a.q_proj, a.k_proj, a.v_proj)):      # column slices of the stacked dqkv
                 sl = dqkv[:, i * aw:(i + 1) * aw]
                 if not padded:
@@ -245,6 +260,8 @@ class _BackboneFn(torch.autograd.Function):
                     gbuf(proj.bias).view(H, dh).add_(tb_.view(H, dhp)[:, :dh], alpha=f)
             _gemm(dqkv, w["wqkvT"], None, dh_buf, M, d, d, 3 * aw, d, 0)
             _ln_bwd(dh_buf, s["x_in"], s["st1"], blk.norm1.weight, dx, dx, gbuf(blk.norm1.weight), gbuf(blk.norm1.bias), M, d)
+        if drop is not None:
+            _ck(lib.bd_dropout_f32(_lib.ptr(dx), _lib.ptr(dx), M, d, _dp(drop), 0, _s()), "bd_dropout_f32")
         _ck(lib.bd_embed_bwd(_lib.ptr(dx), _lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(gbuf(model.token_embedding.weight)),
                              _lib.ptr(gbuf(model.position_embedding.weight)),
                              _lib.ptr(gbuf(model.timestep_embedding.weight)), B, L, d, int(model.pad_token_id), _s()),

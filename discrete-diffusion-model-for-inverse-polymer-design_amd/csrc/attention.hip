@@ -17,6 +17,7 @@
 // accumulator registers of two adjacent 16-key tiles are exactly one k-step of the
 // second product in natural key order.
 #include "bd_common.h"
+#include "bd_drop.h"
 
 namespace {
 
@@ -32,12 +33,12 @@ __device__ __forceinline__ s16x4 lds_read_tr(const unsigned char* p) {
       (__attribute__((address_space(3))) s16x4*)(p));
 }
 
-template <int DH>
+template <int DH, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* __restrict__ qkv,
                                                           const unsigned char* __restrict__ keymask,
                                                           unsigned short* __restrict__ out,
                                                           float* __restrict__ lse_out,
-                                                          int L, int H, float scale) {
+                                                          int L, int H, float scale, bd_drop_args drop) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KT * ROWB + KT];
   unsigned char* const Ks = smem;
   unsigned char* const Vs = smem + KT * ROWB;
@@ -144,6 +145,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
       o[i][0] *= alpha; o[i][1] *= alpha; o[i][2] *= alpha; o[i][3] *= alpha;
     }
 
+    // ---- dropout of the probabilities (the normaliser l_run keeps every visible key)
+    if (DROP) {
+      const uint32_t prow = (uint32_t)(((size_t)b * H + h) * L + (q0 + c));
+#pragma unroll
+      for (int tile = 0; tile < 8; ++tile) {
+        const int key0 = kt0 + 32 * (tile >> 1) + 8 * g + 4 * (tile & 1);
+        const bd_philox_out w = bd_drop_words(drop, prow, (uint32_t)(key0 >> 2));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[tile][r] *= bd_drop_factor(drop, w.v[r]);
+      }
+    }
+
     // ---- P^T fragments: k-step s4 covers keys 32 s4 + 8 g + j = tiles (2 s4, 2 s4 + 1)
     bf16x8 pf[4];
 #pragma unroll
@@ -195,29 +208,39 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
 
 // qkv [B*L, 3*H*DH] bf16, keymask [B, L] bytes (non-zero = visible) or null,
 // out [B*L, H*DH] bf16, lse (optional) [B, H, L] fp32 log-sum-exp of the scaled scores.
-extern "C" int bd_attention_fwd(const void* qkv, const unsigned char* keymask, void* out,
-                                float* lse, int B, int L, int H, int head_dim, void* stream) {
+template <int DH>
+static void launch_attn_fwd(dim3 grid, hipStream_t s, const void* qkv, const unsigned char* keymask, void* out, float* lse,
+                            int L, int H, float scale, const bd_drop_args& da) {
+  if (da.thr != 0u)
+    hipLaunchKernelGGL((attn_fwd_kernel<DH, true>), grid, dim3(256), 0, s, (const unsigned short*)qkv, keymask,
+                       (unsigned short*)out, lse, L, H, scale, da);
+  else
+    hipLaunchKernelGGL((attn_fwd_kernel<DH, false>), grid, dim3(256), 0, s, (const unsigned short*)qkv, keymask,
+                       (unsigned short*)out, lse, L, H, scale, da);
+}
+
+extern "C" int bd_attention_fwd_drop(const void* qkv, const unsigned char* keymask, void* out, float* lse, int B, int L,
+                                     int H, int head_dim, const bd_dropout* drop, unsigned site, void* stream) {
   BD_REQUIRE(qkv && out, "bd_attention_fwd: null operand");
   BD_REQUIRE(B > 0 && L > 0 && H > 0, "bd_attention_fwd: empty shape");
   BD_REQUIRE(B <= 65535 && H <= 65535, "bd_attention_fwd: B and H must be <= 65535");
+  bd_drop_args da;
+  BD_REQUIRE(bd_drop_make(drop, site, &da), "bd_attention_fwd: dropout p=%g outside [0, 1)", (double)drop->p);
+  BD_REQUIRE(da.thr == 0u || (long long)B * H * L < (1ll << 32), "bd_attention_fwd: dropout needs B*H*L < 2^32");
   const float scale = 1.0f / sqrtf((float)head_dim);
-  dim3 grid((L + 63) / 64, H, B), block(256);
+  dim3 grid((L + 63) / 64, H, B);
   hipStream_t s = (hipStream_t)stream;
   switch (head_dim) {
-    case 32:
-      hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, 0, s, (const unsigned short*)qkv, keymask,
-                         (unsigned short*)out, lse, L, H, scale);
-      break;
-    case 64:
-      hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, 0, s, (const unsigned short*)qkv, keymask,
-                         (unsigned short*)out, lse, L, H, scale);
-      break;
-    case 128:
-      hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, block, 0, s, (const unsigned short*)qkv, keymask,
-                         (unsigned short*)out, lse, L, H, scale);
-      break;
+    case 32: launch_attn_fwd<32>(grid, s, qkv, keymask, out, lse, L, H, scale, da); break;
+    case 64: launch_attn_fwd<64>(grid, s, qkv, keymask, out, lse, L, H, scale, da); break;
+    case 128: launch_attn_fwd<128>(grid, s, qkv, keymask, out, lse, L, H, scale, da); break;
     default:
       return bd_fail(BD_ERR_UNSUPPORTED, "bd_attention_fwd: head_dim %d not in {32, 64, 128}", head_dim);
   }
   return bd_check_launch("bd_attention_fwd");
+}
+
+extern "C" int bd_attention_fwd(const void* qkv, const unsigned char* keymask, void* out,
+                                float* lse, int B, int L, int H, int head_dim, void* stream) {
+  return bd_attention_fwd_drop(qkv, keymask, out, lse, B, L, H, head_dim, nullptr, 0u, stream);
 }

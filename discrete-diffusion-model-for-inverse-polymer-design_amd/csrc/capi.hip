@@ -2,6 +2,7 @@
 // libbidiff_hip.so.
 #include "bd_common.h"
 #include "bd_rng.h"
+#include "bd_drop.h"
 #include "bd_prof.h"
 #include "bidiff.h"
 
@@ -52,6 +53,19 @@ extern "C" float bd_host_uniform_select(unsigned long long seed, uint32_t seq, u
 extern "C" float bd_host_uniform_token(unsigned long long seed, uint32_t seq, uint32_t t, uint32_t pos,
                                        uint32_t v) {
   return bd_uniform_token(seed, seq, t, pos, v);
+}
+// Host evaluation of the training-dropout decision stream (the code the kernels run): out[r, c] =
+// keep / (1 - p) of element (r, c) of a site. Returns 0, or -1 for p outside [0, 1).
+extern "C" int bd_host_dropout_factors(const bd_dropout* drop, unsigned site, long long rows, long long cols,
+                                       float* out) {
+  bd_drop_args da;
+  if (!bd_drop_make(drop, site, &da)) return -1;
+  for (long long r = 0; r < rows; ++r)
+    for (long long c4 = 0; 4 * c4 < cols; ++c4) {
+      const bd_philox_out w = bd_drop_words(da, (uint32_t)r, (uint32_t)c4);
+      for (int i = 0; i < 4 && 4 * c4 + i < cols; ++i) out[r * cols + 4 * c4 + i] = bd_drop_factor(da, w.v[i]);
+    }
+  return 0;
 }
 
 // ---- event profiler: pairs of events around selected launches, resolved lazily

@@ -1,6 +1,7 @@
 // Bandwidth-bound kernels of the denoiser forward and the q(x_t|x_0) corruption step.
 #include "bd_common.h"
 #include "bd_rng.h"
+#include "bd_drop.h"
 
 namespace {
 
@@ -13,7 +14,8 @@ __global__ __launch_bounds__(256) void embed_kernel(const long long* __restrict_
                                                     const float* __restrict__ tok,
                                                     const float* __restrict__ pos,
                                                     const float* __restrict__ tim,
-                                                    float* __restrict__ x, int M, int L, int d) {
+                                                    float* __restrict__ x, int M, int L, int d,
+                                                    bd_drop_args drop) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -28,7 +30,33 @@ __global__ __launch_bounds__(256) void embed_kernel(const long long* __restrict_
     f32x4 r;
     r[0] = (va[0] + vb[0]) + vc[0]; r[1] = (va[1] + vb[1]) + vc[1];
     r[2] = (va[2] + vb[2]) + vc[2]; r[3] = (va[3] + vb[3]) + vc[3];
+    if (drop.thr != 0u) {
+      const bd_philox_out w = bd_drop_words(drop, (uint32_t)row, (uint32_t)i);
+      r[0] *= bd_drop_factor(drop, w.v[0]); r[1] *= bd_drop_factor(drop, w.v[1]);
+      r[2] *= bd_drop_factor(drop, w.v[2]); r[3] *= bd_drop_factor(drop, w.v[3]);
+    }
     o[i] = r;
+  }
+}
+
+// out[m, n] = x[m, n] * keep / (1 - p), fp32 or bf16 result; one thread per four columns
+template <bool BF16_OUT>
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, void* __restrict__ out,
+                                                      long long n4, int N4, bd_drop_args drop) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const uint32_t row = (uint32_t)(i / N4), c4 = (uint32_t)(i % N4);
+    f32x4 v = ((const f32x4*)x)[i];
+    const bd_philox_out w = bd_drop_words(drop, row, c4);
+    v[0] *= bd_drop_factor(drop, w.v[0]); v[1] *= bd_drop_factor(drop, w.v[1]);
+    v[2] *= bd_drop_factor(drop, w.v[2]); v[3] *= bd_drop_factor(drop, w.v[3]);
+    if (BF16_OUT) {
+      u32x2 o;
+      o[0] = bd_pack_bf16x2(v[0], v[1]); o[1] = bd_pack_bf16x2(v[2], v[3]);
+      ((u32x2*)out)[i] = o;
+    } else {
+      ((f32x4*)out)[i] = v;
+    }
   }
 }
 
@@ -130,14 +158,44 @@ __global__ __launch_bounds__(256) void mask_to_bytes_kernel(const long long* __r
 }  // namespace
 
 extern "C" int bd_embed(const long long* ids, const long long* timesteps, const float* tok_emb,
-                        const float* pos_emb, const float* time_emb, float* x, int B, int L, int d,
-                        void* stream) {
+                        const float* pos_emb, const float* time_emb, float* x, int B, int L, int d, void* stream) {
+  return bd_embed_drop(ids, timesteps, tok_emb, pos_emb, time_emb, x, B, L, d, nullptr, 0u, stream);
+}
+
+static int dropout_launch(const float* x, void* out, int M, int N, const bd_dropout* drop, unsigned site, bool bf16,
+                          void* stream) {
+  BD_REQUIRE(x && out, "bd_dropout: null operand");
+  BD_REQUIRE(M > 0 && N > 0 && N % 4 == 0, "bd_dropout: bad shape M=%d N=%d", M, N);
+  bd_drop_args da;
+  BD_REQUIRE(bd_drop_make(drop, site, &da), "bd_dropout: p=%g outside [0, 1)", (double)drop->p);
+  const long long n4 = (long long)M * (N / 4);
+  const unsigned grid = (unsigned)((n4 + 255) / 256 < 65536 ? (n4 + 255) / 256 : 65536);
+  if (bf16) hipLaunchKernelGGL(dropout_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, out, n4, N / 4, da);
+  else hipLaunchKernelGGL(dropout_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, out, n4, N / 4, da);
+  return bd_check_launch("bd_dropout");
+}
+
+extern "C" int bd_dropout_f32(const float* x, float* out, int M, int N, const bd_dropout* drop, unsigned site,
+                              void* stream) {
+  return dropout_launch(x, out, M, N, drop, site, false, stream);
+}
+
+extern "C" int bd_dropout_f32_to_bf16(const float* x, void* out, int M, int N, const bd_dropout* drop, unsigned site,
+                                      void* stream) {
+  return dropout_launch(x, out, M, N, drop, site, true, stream);
+}
+
+extern "C" int bd_embed_drop(const long long* ids, const long long* timesteps, const float* tok_emb,
+                             const float* pos_emb, const float* time_emb, float* x, int B, int L, int d,
+                             const bd_dropout* drop, unsigned site, void* stream) {
   BD_REQUIRE(ids && timesteps && tok_emb && pos_emb && time_emb && x, "bd_embed: null operand");
+  bd_drop_args da;
+  BD_REQUIRE(bd_drop_make(drop, site, &da), "bd_embed: dropout p=%g outside [0, 1)", (double)drop->p);
   BD_REQUIRE(B > 0 && L > 0 && d > 0 && d % 4 == 0, "bd_embed: bad shape B=%d L=%d d=%d", B, L, d);
   const long long M = (long long)B * L;
   BD_REQUIRE(M < (1ll << 31), "bd_embed: too many tokens");
   hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ids,
-                     timesteps, tok_emb, pos_emb, time_emb, x, (int)M, L, d);
+                     timesteps, tok_emb, pos_emb, time_emb, x, (int)M, L, d, da);
   return bd_check_launch("bd_embed");
 }
 

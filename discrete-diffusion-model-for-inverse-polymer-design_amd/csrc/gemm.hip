@@ -11,6 +11,7 @@
 // consecutive n: the epilogue stores 16-byte vectors straight from registers.
 #include "bd_common.h"
 #include "bd_prof.h"
+#include "bd_drop.h"
 
 namespace {
 
@@ -34,6 +35,7 @@ struct GemmArgs {
   void* aux_out;             // EPI 1: optional bf16 copy of the pre-activation (acc + bias)
   int M, Npad, K, n_real, ldc;
   int tiles_n, n_tiles;
+  bd_drop_args drop;         // DROP kernels: dropout of the epilogue value at (row m, column n)
 };
 
 __device__ __forceinline__ int swz_a(int row) { return row & 7; }
@@ -60,7 +62,17 @@ __device__ __forceinline__ float gelu_grad(float x) {
   return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 
-template <int EPI>
+// keep / (1 - p) factors of the 16 consecutive columns nb .. nb + 15 of row m
+__device__ __forceinline__ void drop_factors16(const bd_drop_args& d, int m, int nb, float (&f)[16]) {
+#pragma unroll
+  for (int j4 = 0; j4 < 4; ++j4) {
+    const bd_philox_out w = bd_drop_words(d, (uint32_t)m, (uint32_t)(nb >> 2) + j4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) f[4 * j4 + r] = bd_drop_factor(d, w.v[r]);
+  }
+}
+
+template <int EPI, bool DROP>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];
   unsigned char* const As = smem;                   // 2 buffers
@@ -206,6 +218,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = gelu_erf(v[j]);
       }
+      if (DROP) {
+        float f[16];
+        drop_factors16(p.drop, m, nb, f);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] *= f[j];
+      }
       if (EPI == EPI_DGELU_BF16) {
         const unsigned short* ui = (const unsigned short*)p.aux_in + (size_t)m * p.ldc + nb;
         const u32x4 lo = *(const u32x4*)(ui), hi = *(const u32x4*)(ui + 8);
@@ -228,6 +246,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     } else if (EPI == EPI_BIAS_RESID_F32) {
       float* o = (float*)p.out + (size_t)m * p.ldc + nb;
       const float* ri = p.aux_in ? (const float*)p.aux_in + (size_t)m * p.ldc + nb : o;
+      if (DROP) {
+        float f[16];
+        drop_factors16(p.drop, m, nb, f);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] *= f[j];
+      }
 #pragma unroll
       for (int j4 = 0; j4 < 4; ++j4) {
         f32x4 x = *(const f32x4*)(ri + 4 * j4);
@@ -243,10 +267,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
   }
 }
 
-template <int EPI>
+template <int EPI, bool DROP = false>
 int launch(const GemmArgs& a, hipStream_t s) {
   void* tok = bd_prof_on() ? bd_prof_begin(s) : nullptr;
-  hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(a.n_tiles), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, DROP>), dim3(a.n_tiles), dim3(256), 0, s, a);
   if (tok) bd_prof_end(tok, s, 2.0 * (double)a.M * (double)a.n_real * (double)a.K);
   return bd_check_launch("bd_gemm_bf16");
 }
@@ -255,9 +279,9 @@ int launch(const GemmArgs& a, hipStream_t s) {
 
 // epilogue: 0 bias->bf16, 1 bias+gelu->bf16, 2 fp32 out = resid + acc+bias, 3 fp32 out (ragged n),
 //           4 bf16 out = (acc+bias) * gelu'(aux_in)
-extern "C" int bd_gemm_bf16_aux(const void* A, const void* W, const float* bias, void* out,
-                                const void* aux_in, void* aux_out, int M, int n_pad, int n_real, int K,
-                                int ldc, int epilogue, void* stream) {
+extern "C" int bd_gemm_bf16_drop(const void* A, const void* W, const float* bias, void* out,
+                                 const void* aux_in, void* aux_out, int M, int n_pad, int n_real, int K,
+                                 int ldc, int epilogue, const bd_dropout* drop, unsigned site, void* stream) {
   BD_REQUIRE(A && W && out, "bd_gemm_bf16: null operand");
   BD_REQUIRE(epilogue >= 0 && epilogue <= 4, "bd_gemm_bf16: unknown epilogue %d", epilogue);
   BD_REQUIRE(M > 0 && K > 0 && n_pad > 0, "bd_gemm_bf16: empty shape M=%d N=%d K=%d", M, n_pad, K);
@@ -278,6 +302,15 @@ extern "C" int bd_gemm_bf16_aux(const void* A, const void* W, const float* bias,
   BD_REQUIRE(nt < (1ll << 31), "bd_gemm_bf16: too many tiles");
   a.n_tiles = (int)nt;
   hipStream_t s = (hipStream_t)stream;
+  BD_REQUIRE(bd_drop_make(drop, site, &a.drop), "bd_gemm_bf16: dropout p=%g outside [0, 1)", (double)drop->p);
+  if (a.drop.thr != 0u) {
+    switch (epilogue) {
+      case EPI_BIAS_GELU_BF16: return launch<EPI_BIAS_GELU_BF16, true>(a, s);
+      case EPI_BIAS_RESID_F32: return launch<EPI_BIAS_RESID_F32, true>(a, s);
+      case EPI_DGELU_BF16: return launch<EPI_DGELU_BF16, true>(a, s);
+      default: return bd_fail(BD_ERR_ARG, "bd_gemm_bf16: epilogue %d has no dropout", epilogue);
+    }
+  }
   switch (epilogue) {
     case EPI_BIAS_BF16: return launch<EPI_BIAS_BF16>(a, s);
     case EPI_BIAS_GELU_BF16: return launch<EPI_BIAS_GELU_BF16>(a, s);
@@ -286,6 +319,12 @@ extern "C" int bd_gemm_bf16_aux(const void* A, const void* W, const float* bias,
     case EPI_DGELU_BF16: return launch<EPI_DGELU_BF16>(a, s);
     default: return bd_fail(BD_ERR_ARG, "bd_gemm_bf16: unknown epilogue %d", epilogue);
   }
+}
+
+extern "C" int bd_gemm_bf16_aux(const void* A, const void* W, const float* bias, void* out,
+                                const void* aux_in, void* aux_out, int M, int n_pad, int n_real, int K,
+                                int ldc, int epilogue, void* stream) {
+  return bd_gemm_bf16_drop(A, W, bias, out, aux_in, aux_out, M, n_pad, n_real, K, ldc, epilogue, nullptr, 0u, stream);
 }
 
 extern "C" int bd_gemm_bf16(const void* A, const void* W, const float* bias, void* out, int M, int n_pad,

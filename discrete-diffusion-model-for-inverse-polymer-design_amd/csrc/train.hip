@@ -2,6 +2,7 @@
 // weight-gradient GEMM, bias column sums, attention backward, embedding backward, global
 // gradient norm and the fused AdamW update.
 #include "bd_common.h"
+#include "bd_drop.h"
 #include "bidiff.h"
 
 namespace {
@@ -340,7 +341,7 @@ __device__ __forceinline__ void stage_rows(unsigned char* dst, const unsigned sh
   }
 }
 
-template <int DH>
+template <int DH, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned short* __restrict__ qkv,
                                                              const unsigned char* __restrict__ keymask,
                                                              const unsigned short* __restrict__ O,
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned shor
                                                              const float* __restrict__ lse,
                                                              float* __restrict__ delta,
                                                              unsigned short* __restrict__ dqkv, int L, int H,
-                                                             float scale) {
+                                                             float scale, bd_drop_args drop) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * AT * AROW + AT];
   unsigned char* const Ks = smem;
   unsigned char* const Vs = smem + AT * AROW;
@@ -416,6 +417,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned shor
         }
         const int kb = 32 * s4 + 8 * g + 4 * half;
         const unsigned int m4 = *(const unsigned int*)(Ms + kb);
+        if (DROP) {   // dP = (dO V^T) * keep / (1 - p)
+          const bd_philox_out w = bd_drop_words(drop, (uint32_t)(((size_t)b * H + h) * L + qr), (uint32_t)((kt0 + kb) >> 2));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dp[r] *= bd_drop_factor(drop, w.v[r]);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const bool vis = ((m4 >> (8 * r)) & 0xffu) != 0u && lq > -INFINITY;
@@ -449,14 +455,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned shor
   }
 }
 
-template <int DH>
+template <int DH, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const unsigned short* __restrict__ qkv,
                                                               const unsigned char* __restrict__ keymask,
                                                               const unsigned short* __restrict__ dO,
                                                               const float* __restrict__ lse,
                                                               const float* __restrict__ delta,
                                                               unsigned short* __restrict__ dqkv, int L, int H,
-                                                              float scale) {
+                                                              float scale, bd_drop_args drop) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * AT * AROW + 2 * AT * 4];
   unsigned char* const Qs = smem;
   unsigned char* const Ds = smem + AT * AROW;
@@ -499,6 +505,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const unsigned sho
       Dl[tid] = q < L ? delta[((size_t)b * H + h) * L + q] : 0.f;
     }
     __syncthreads();
+    // keep decisions of the lane's key against this lane's 32 queries of the tile, one Philox block
+    // per query (the block holds four neighbouring KEYS); a rolled loop keeps the registers free
+    uint32_t keepbits = 0u;
+    if (DROP) {
+      const uint32_t prow0 = (uint32_t)(((size_t)b * H + h) * L + qt0 + 8 * g);
+#pragma nounroll
+      for (int i = 0; i < 32; ++i) {
+        const bd_philox_out w = bd_drop_words(drop, prow0 + 32 * (i >> 3) + (i & 7), (uint32_t)(kr >> 2));
+        const uint32_t lo = (kr & 1) ? w.v[1] : w.v[0], hi = (kr & 1) ? w.v[3] : w.v[2];
+        keepbits |= (uint32_t)(((kr & 2) ? hi : lo) >= drop.thr) << i;
+      }
+    }
     bf16x8 pf[4], dsf[4];
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
@@ -520,8 +538,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const unsigned sho
           const float lq = Ls[qb + r];
           const bool on = vis && lq > -INFINITY && lq < INFINITY;
           const float p = on ? __expf(s[r] * scale - lq) : 0.f;
-          fp[4 * half + r] = (__bf16)p;
-          fd[4 * half + r] = (__bf16)(p * (dp[r] - Dl[qb + r]) * scale);
+          const float z = !DROP ? 1.0f : (((keepbits >> (8 * s4 + 4 * half + r)) & 1u) ? drop.scale : 0.f);
+          fp[4 * half + r] = (__bf16)(p * z);
+          fd[4 * half + r] = (__bf16)(p * (dp[r] * z - Dl[qb + r]) * scale);
         }
       }
       pf[s4] = fp;
@@ -704,8 +723,17 @@ extern "C" int bd_colsum_bf16(const void* dY, int ld, float* out, int M, int N, 
 extern "C" int bd_attention_bwd(const void* qkv, const unsigned char* keymask, const void* out, const void* dout,
                                 const float* lse, float* delta, void* dqkv, int B, int L, int H, int head_dim,
                                 void* stream) {
+  return bd_attention_bwd_drop(qkv, keymask, out, dout, lse, delta, dqkv, B, L, H, head_dim, nullptr, 0u, stream);
+}
+
+extern "C" int bd_attention_bwd_drop(const void* qkv, const unsigned char* keymask, const void* out, const void* dout,
+                                     const float* lse, float* delta, void* dqkv, int B, int L, int H, int head_dim,
+                                     const bd_dropout* drop, unsigned site, void* stream) {
   BD_REQUIRE(qkv && out && dout && lse && delta && dqkv, "bd_attention_bwd: null operand");
   BD_REQUIRE(B > 0 && L > 0 && H > 0 && B <= 65535 && H <= 65535, "bd_attention_bwd: bad shape");
+  bd_drop_args da;
+  BD_REQUIRE(bd_drop_make(drop, site, &da), "bd_attention_bwd: dropout p=%g outside [0, 1)", (double)drop->p);
+  BD_REQUIRE(da.thr == 0u || (long long)B * H * L < (1ll << 32), "bd_attention_bwd: dropout needs B*H*L < 2^32");
   const float scale = 1.0f / sqrtf((float)head_dim);
   dim3 grid((L + 63) / 64, H, B), block(256);
   hipStream_t s = (hipStream_t)stream;
@@ -713,9 +741,14 @@ extern "C" int bd_attention_bwd(const void* qkv, const unsigned char* keymask, c
   const unsigned short* o = (const unsigned short*)out;
   const unsigned short* dO = (const unsigned short*)dout;
   unsigned short* dq = (unsigned short*)dqkv;
-#define BD_LAUNCH_BWD(DH)                                                                                   \
-  hipLaunchKernelGGL(attn_bwd_dq_kernel<DH>, grid, block, 0, s, q, keymask, o, dO, lse, delta, dq, L, H, scale); \
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel<DH>, grid, block, 0, s, q, keymask, dO, lse, delta, dq, L, H, scale)
+#define BD_LAUNCH_BWD(DH)                                                                                        \
+  if (da.thr != 0u) {                                                                                            \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, true>), grid, block, 0, s, q, keymask, o, dO, lse, delta, dq, L, H, scale, da);  \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, true>), grid, block, 0, s, q, keymask, dO, lse, delta, dq, L, H, scale, da);    \
+  } else {                                                                                                       \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, false>), grid, block, 0, s, q, keymask, o, dO, lse, delta, dq, L, H, scale, da); \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, false>), grid, block, 0, s, q, keymask, dO, lse, delta, dq, L, H, scale, da);   \
+  }
   switch (head_dim) {
     case 32: BD_LAUNCH_BWD(32); break;
     case 64: BD_LAUNCH_BWD(64); break;

@@ -210,6 +210,42 @@ int bd_corrupt(const long long* ids, const long long* attention_mask, const long
 
 /* ---------------------------------------------------------------- training step */
 
+/* Training dropout (nn.Dropout / SDPA dropout_p, src/model/backbone.py:30,65,93,98,100,185,247).
+ * Keep decisions are a pure function of (seed, step, site, row, column): one Philox4x32-10 block
+ * with counter (column / 4, row, site, step) and key = seed holds the 32-bit words of four
+ * neighbouring columns; an element is kept iff its word >= floor(p * 2^32) and is then scaled by
+ * 1 / (1 - p). Forward and backward kernels regenerate the decisions, nothing is stored; a caller
+ * bumps `step` once per forward pass. A null bd_dropout or p == 0 is the identity.
+ * Sites of the denoiser (rows x columns): 0 = embedding sum [B*L, d]; for block i:
+ * 4 i + 1 = attention probabilities [(b H + h) L + query, key], 4 i + 2 = GELU output [B*L, F],
+ * 4 i + 3 = fc2 output [B*L, d]. */
+typedef struct bd_dropout {
+  float p;
+  unsigned step;
+  unsigned long long seed;
+} bd_dropout;
+
+/* out = x * keep / (1 - p) over [M, N] fp32 (out may alias x); N % 4 == 0. */
+int bd_dropout_f32(const float* x, float* out, int M, int N, const bd_dropout* drop, unsigned site,
+                   void* stream);
+/* The same with a bf16 result. */
+int bd_dropout_f32_to_bf16(const float* x, void* out_bf16, int M, int N, const bd_dropout* drop,
+                           unsigned site, void* stream);
+
+/* bd_embed followed by dropout of the sum (src/model/backbone.py:247). */
+int bd_embed_drop(const long long* ids, const long long* timesteps, const float* tok_emb,
+                  const float* pos_emb, const float* time_emb, float* x, int B, int L, int d,
+                  const bd_dropout* drop, unsigned site, void* stream);
+
+/* bd_gemm_bf16_aux with dropout in the epilogue (row = m, column = n of the output):
+ *   epilogue 1: out = drop(gelu(acc + bias))            (src/model/backbone.py:97-98)
+ *   epilogue 2: out = aux_in + drop(acc + bias)         (src/model/backbone.py:99-100,128)
+ *   epilogue 4: out = (acc + bias) * keep / (1 - p) * gelu'(aux_in)    (backward of epilogue 1)
+ * other epilogues reject a non-null drop with p > 0. */
+int bd_gemm_bf16_drop(const void* A, const void* W, const float* bias, void* out, const void* aux_in,
+                      void* aux_out, int M, int n_pad, int n_real, int K, int ldc, int epilogue,
+                      const bd_dropout* drop, unsigned site, void* stream);
+
 /* Masked cross-entropy (fp32): weight w[m] = indicator[m] * attention_mask[m] (1 without a mask);
  * forward adds sum(ce * w) to sums[0] and sum(w) to sums[1] (caller zeroes sums) and stores the
  * per-row log-sum-exp; backward writes dlogits = grad_out[0] * w / sums[1] * (softmax - onehot),
@@ -240,6 +276,16 @@ int bd_colsum_bf16(const void* dY, int ld, float* out, int M, int N, void* strea
 int bd_attention_bwd(const void* qkv, const unsigned char* keymask, const void* out, const void* dout,
                      const float* lse, float* delta, void* dqkv, int B, int L, int H, int head_dim,
                      void* stream);
+
+/* bd_attention_fwd / bd_attention_bwd with dropout of the attention probabilities
+ * (F.scaled_dot_product_attention(dropout_p), src/model/backbone.py:59-66): the softmax is
+ * normalised over all visible keys, then each probability is dropped or scaled. `out` given to
+ * the backward is the forward's (dropped) output. */
+int bd_attention_fwd_drop(const void* qkv, const unsigned char* keymask, void* out, float* lse, int B,
+                          int L, int H, int head_dim, const bd_dropout* drop, unsigned site, void* stream);
+int bd_attention_bwd_drop(const void* qkv, const unsigned char* keymask, const void* out, const void* dout,
+                          const float* lse, float* delta, void* dqkv, int B, int L, int H, int head_dim,
+                          const bd_dropout* drop, unsigned site, void* stream);
 
 /* Scatter-add of the embedding-sum gradient into the three tables (the pad row of the token table
  * receives nothing, as nn.Embedding(padding_idx) does). (autograd of src/model/backbone.py:234-246). */
@@ -346,6 +392,8 @@ int bd_sample_fixup(const bd_fix_args* args, void* stream);
 void bd_host_gumbel(const float* u, float* out, long long n);
 void bd_host_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                     uint32_t out[4]);
+/* Host evaluation of the training-dropout decision stream: out[r * cols + c] = keep / (1 - p). */
+int bd_host_dropout_factors(const bd_dropout* drop, unsigned site, long long rows, long long cols, float* out);
 float bd_host_uniform_select(unsigned long long seed, uint32_t seq, uint32_t t, uint32_t pos);
 float bd_host_uniform_token(unsigned long long seed, uint32_t seq, uint32_t t, uint32_t pos,
                             uint32_t v);

@@ -6,7 +6,10 @@ Follows Bi_Diffusion_SMILES/src/model/backbone.py:
   a fully masked query row gives an all-zero attention output), FFN :95-101 (erf GELU),
   final norm + vocabulary projection :254-255;
 and Bi_Diffusion_SMILES/src/model/diffusion.py: schedule :60-71, loss :169-209.
-Dropout is the identity (eval mode / dropout=0).
+Dropout is the identity (eval mode / dropout=0) unless a ``DropoutStream`` is passed: then the
+four dropout sites of the reference (embedding sum :247, attention probabilities :65, GELU output
+:98, fc2 output :100) multiply by the factors of the counter-based decision stream that the device
+kernels regenerate (``sampler_ref.dropout_mask``), so both sides drop the same elements.
 """
 import math
 
@@ -14,7 +17,21 @@ import torch
 import torch.nn.functional as F
 
 
-def attention(x, sd, prefix, num_heads, attention_mask):
+class DropoutStream:
+    """Dropout factors (0 or 1 / (1 - p)) per site: 0 = embedding sum [B*L, d]; block i:
+    4 i + 1 = attention probabilities [(b H + h) L + query, key], 4 i + 2 = GELU output [B*L, F],
+    4 i + 3 = fc2 output [B*L, d]."""
+
+    def __init__(self, p, seed, step=0):
+        self.p, self.seed, self.step = float(p), int(seed), int(step)
+
+    def factors(self, site, rows, cols, like):
+        from . import sampler_ref
+        m = sampler_ref.dropout_mask(self.seed, self.step, site, self.p, rows, cols)
+        return torch.from_numpy(m).to(device=like.device, dtype=like.dtype)
+
+
+def attention(x, sd, prefix, num_heads, attention_mask, dropout=None, site=0):
     B, L, d = x.shape
     dh = d // num_heads
 
@@ -29,11 +46,14 @@ def attention(x, sd, prefix, num_heads, attention_mask):
         scores = scores.masked_fill(~vis, float("-inf"))
     probs = torch.softmax(scores, dim=-1)
     probs = torch.nan_to_num(probs, nan=0.0)      # all keys masked -> zero output row
+    if dropout is not None:
+        probs = probs * dropout.factors(site, B * num_heads * L, L, probs).view(B, num_heads, L, L)
     out = torch.matmul(probs, v).transpose(1, 2).contiguous().view(B, L, d)
     return F.linear(out, sd[f"{prefix}.out_proj.weight"], sd[f"{prefix}.out_proj.bias"])
 
 
-def hidden_states(sd, cfg, input_ids, timesteps, attention_mask=None, prefix="", eps=1e-5, layer_idx=-1):
+def hidden_states(sd, cfg, input_ids, timesteps, attention_mask=None, prefix="", eps=1e-5, layer_idx=-1,
+                  dropout=None):
     """Hidden states [B, L, d] (fp32): final-norm output for ``layer_idx == -1``, otherwise the residual
     stream after block ``layer_idx`` without the final norm (reference backbone.py:291-299)."""
     p = prefix
@@ -44,21 +64,28 @@ def hidden_states(sd, cfg, input_ids, timesteps, attention_mask=None, prefix="",
     pos = torch.arange(L, device=input_ids.device)
     x = (sd[p + "token_embedding.weight"][input_ids] + sd[p + "position_embedding.weight"][pos][None]
          + sd[p + "timestep_embedding.weight"][timesteps][:, None, :])
+    if dropout is not None:
+        x = x * dropout.factors(0, B * L, d, x).view(B, L, d)
     for i in range(cfg["num_layers"] if layer_idx == -1 else layer_idx + 1):
         lp = f"{p}layers.{i}"
         h = F.layer_norm(x, (d,), sd[f"{lp}.norm1.weight"], sd[f"{lp}.norm1.bias"], eps)
-        x = x + attention(h, sd, f"{lp}.attn", cfg["num_heads"], attention_mask)
+        x = x + attention(h, sd, f"{lp}.attn", cfg["num_heads"], attention_mask, dropout, 4 * i + 1)
         h = F.layer_norm(x, (d,), sd[f"{lp}.norm2.weight"], sd[f"{lp}.norm2.bias"], eps)
         h = F.linear(h, sd[f"{lp}.ffn.fc1.weight"], sd[f"{lp}.ffn.fc1.bias"])
         h = F.gelu(h)
-        x = x + F.linear(h, sd[f"{lp}.ffn.fc2.weight"], sd[f"{lp}.ffn.fc2.bias"])
+        if dropout is not None:
+            h = h * dropout.factors(4 * i + 2, B * L, h.shape[-1], h).view_as(h)
+        h = F.linear(h, sd[f"{lp}.ffn.fc2.weight"], sd[f"{lp}.ffn.fc2.bias"])
+        if dropout is not None:
+            h = h * dropout.factors(4 * i + 3, B * L, d, h).view_as(h)
+        x = x + h
     if layer_idx != -1:
         return x
     return F.layer_norm(x, (d,), sd[p + "final_norm.weight"], sd[p + "final_norm.bias"], eps)
 
 
-def logits(sd, cfg, input_ids, timesteps, attention_mask=None, prefix=""):
-    h = hidden_states(sd, cfg, input_ids, timesteps, attention_mask, prefix)
+def logits(sd, cfg, input_ids, timesteps, attention_mask=None, prefix="", dropout=None):
+    h = hidden_states(sd, cfg, input_ids, timesteps, attention_mask, prefix, dropout=dropout)
     return F.linear(h, sd[prefix + "output_proj.weight"])
 
 

@@ -57,8 +57,7 @@ def build():
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
-            build()
+        build()
         h = C.CDLL(_SO)
         h.ora_sample_step.restype = C.c_int
         h.ora_sample_step.argtypes = [C.POINTER(StepArgs)]
@@ -72,6 +71,8 @@ def lib():
         h.ora_uniform_select.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
         h.ora_uniform_token.restype = C.c_float
         h.ora_uniform_token.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        h.ora_dropout_mask.restype = None
+        h.ora_dropout_mask.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_float, C.c_longlong, C.c_longlong, VP]
         h.ora_corrupt.restype = C.c_int
         h.ora_corrupt.argtypes = [VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.c_uint64, C.c_longlong]
@@ -101,6 +102,13 @@ def philox(c, k):
     out = (C.c_uint32 * 4)()
     lib().ora_philox(c[0], c[1], c[2], c[3], k[0], k[1], out)
     return [int(x) for x in out]
+
+
+def dropout_mask(seed, step, site, p, rows, cols):
+    """fp32 [rows, cols] of dropout factors (0 or 1 / (1 - p)) of one site of the decision stream."""
+    out = np.empty((rows, cols), dtype=np.float32)
+    lib().ora_dropout_mask(int(seed), int(step), int(site), float(p), rows, cols, _p(out))
+    return out
 
 
 def corrupt(ids, attn, t, schedule, uniforms, mask_id, pad_id, bos_id, eos_id, seed=0, seq_offset=0):

@@ -57,6 +57,26 @@ def test_gumbel_transform_bitwise_across_library_oracle_numpy():
     assert np.abs(out[4:] - ref[4:]).max() < 2e-6
 
 
+def test_dropout_decision_stream_library_equals_oracle():
+    """The library's host evaluation of the training-dropout stream (the code the kernels run) and
+    the oracle's agree bit for bit, ragged column counts included; the keep rate is 1 - p."""
+    for (p, step, site, seed, rows, cols) in [(0.1, 0, 0, 1, 50, 128), (0.1, 7, 13, 2 ** 63 + 5, 33, 30),
+                                               (0.5, 2 ** 32 - 1, 4 * 31 + 3, 2 ** 64 - 1, 9, 5), (0.0, 1, 1, 1, 4, 8)]:
+        d = _lib.Dropout(p, step, seed)
+        out = np.empty((rows, cols), dtype=np.float32)
+        assert _lib.lib().bd_host_dropout_factors(C.byref(d), site, rows, cols, out.ctypes.data_as(C.c_void_p)) == 0
+        want = ora.dropout_mask(seed, step, site, p, rows, cols)
+        assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+        assert set(np.unique(out)) <= {np.float32(0.0), np.float32(1.0) / (np.float32(1.0) - np.float32(p))}
+    big = ora.dropout_mask(42, 3, 2, 0.1, 2000, 512)
+    assert abs(float((big == 0).mean()) - 0.1) < 2e-3
+    assert abs(float(big.mean()) - 1.0) < 2e-3
+    # rows and 4-column groups are independent draws: no repeated row pattern
+    assert len({r.tobytes() for r in (big[:200] == 0)}) == 200
+    assert _lib.lib().bd_host_dropout_factors(C.byref(_lib.Dropout(1.0, 0, 0)), 0, 1, 4,
+                                              np.empty(4, np.float32).ctypes.data_as(C.c_void_p)) == -1
+
+
 def test_uniform_streams_match_oracle():
     lib, olib = _lib.lib(), ora.lib()
     for seed in (0, 42, 2**61 + 12345):
