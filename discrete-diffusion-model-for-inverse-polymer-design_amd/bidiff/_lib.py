@@ -114,6 +114,7 @@ SIGNATURES = {
     "bd_masked_ce_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, VP]),
     "bd_layernorm_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, VP]),
     "bd_gemm_wgrad_bf16": (C.c_int, [VP, C.c_int, VP, C.c_int, VP, C.c_int, C.c_int, C.c_int, VP]),
+    "bd_gemm_wgrad_segments": (C.c_int, [VP, C.c_int, VP, C.c_int, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "bd_colsum_bf16": (C.c_int, [VP, C.c_int, VP, C.c_int, C.c_int, VP]),
     "bd_attention_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "bd_embed_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),

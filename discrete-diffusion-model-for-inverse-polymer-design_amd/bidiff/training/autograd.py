@@ -45,9 +45,16 @@ def _ln_bwd(dy, x, stats, g, dres, dx, dg, db, M, d):
                                     _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), M, d, _s()), "bd_layernorm_bwd")
 
 
-def _wgrad(dY, X, dW, M, N, K):
-    _ck(_lib.lib().bd_gemm_wgrad_bf16(_lib.ptr(dY), dY.stride(0), _lib.ptr(X), X.stride(0), _lib.ptr(dW), M, N, K,
-                                      _s()), "bd_gemm_wgrad_bf16")
+def _wgrad(dY, X, dW, M, N, K, db=None):
+    """dW += dY^T X and (optionally) db += column sums of dY, one launch. ``dW`` / ``db`` may be lists of
+    up to three destinations for equal row segments of dY (the stacked q | k | v gradient)."""
+    dws = dW if isinstance(dW, (list, tuple)) else [dW]
+    dbs = db if isinstance(db, (list, tuple)) else ([db] if db is not None else None)
+    n = len(dws)
+    pw = (C.c_void_p * n)(*[t.data_ptr() for t in dws])
+    pb = None if dbs is None else (C.c_void_p * n)(*[t.data_ptr() for t in dbs])
+    _ck(_lib.lib().bd_gemm_wgrad_segments(_lib.ptr(dY), dY.stride(0), _lib.ptr(X), X.stride(0), pw, pb, n, N // n, M, K,
+                                          _s()), "bd_gemm_wgrad_segments")
 
 
 def _colsum(dY, out, M, N):
@@ -226,38 +233,33 @@ class _BackboneFn(torch.autograd.Function):
             a = blk.attn
             # x_out = x_mid + drop(fc2(drop(gelu(fc1(LN2(x_mid))))))
             _to_bf16(dx, dy, drop, 4 * li + 3)
-            _wgrad(dy, s["a"], gbuf(blk.ffn.fc2.weight), M, d, F)
-            _colsum(dy, gbuf(blk.ffn.fc2.bias), M, d)
+            _wgrad(dy, s["a"], gbuf(blk.ffn.fc2.weight), M, d, F, db=gbuf(blk.ffn.fc2.bias))
             _gemm(dy, w["w2T"], None, du, M, F, F, d, F, 4, aux_in=s["u"], drop=drop, site=4 * li + 2)
-            _wgrad(du, s["h2"], gbuf(blk.ffn.fc1.weight), M, F, d)
-            _colsum(du, gbuf(blk.ffn.fc1.bias), M, F)
+            _wgrad(du, s["h2"], gbuf(blk.ffn.fc1.weight), M, F, d, db=gbuf(blk.ffn.fc1.bias))
             _gemm(du, w["w1T"], None, dh_buf, M, d, d, F, d, 0)
             _ln_bwd(dh_buf, s["x_mid"], s["st2"], blk.norm2.weight, dx, dx, gbuf(blk.norm2.weight), gbuf(blk.norm2.bias), M, d)
             # x_mid = x_in + out_proj(attention(qkv(LN1(x_in))))
             _to_bf16(dx, dy)
             if not padded:
-                _wgrad(dy, s["att"], gbuf(a.out_proj.weight), M, d, d)
+                _wgrad(dy, s["att"], gbuf(a.out_proj.weight), M, d, d, db=gbuf(a.out_proj.bias))
             else:       # gradient of the zero-padded weight, real columns added to the parameter's
                 tmp = zeros(d, aw)
-                _wgrad(dy, s["att"], tmp, M, d, aw)
+                _wgrad(dy, s["att"], tmp, M, d, aw, db=gbuf(a.out_proj.bias))
                 gbuf(a.out_proj.weight).view(d, H, dh).add_(tmp.view(d, H, dhp)[:, :, :dh])
-            _colsum(dy, gbuf(a.out_proj.bias), M, d)
             _gemm(dy, w["woT"], None, datt, M, aw, aw, d, aw, 0)
             _ck(lib.bd_attention_bwd_drop(_lib.ptr(s["qkv"]), _lib.ptr(keymask), _lib.ptr(s["att"]), _lib.ptr(datt),
                                           _lib.ptr(s["lse"]), _lib.ptr(delta), _lib.ptr(dqkv), B, L, H, aw // H,
                                           _dp(drop), 4 * li + 1, _s()), "bd_attention_bwd")
-            for i, proj in enumerate((a.q_proj, a.k_proj, a.v_proj)):      # column slices of the stacked dqkv
-                sl = dqkv[:, i * aw:(i + 1) * aw]
-                if not padded:
-                    _wgrad(sl, s["h1"], gbuf(proj.weight), M, d, d)
-                    _colsum(sl, gbuf(proj.bias), M, d)
-                else:   # rows of the padded projection; the q rows were scaled by qfix in the forward
-                    tw_, tb_ = zeros(aw, d), zeros(aw)
-                    _wgrad(sl, s["h1"], tw_, M, aw, d)
-                    _colsum(sl, tb_, M, aw)
+            projs = (a.q_proj, a.k_proj, a.v_proj)
+            if not padded:      # the three row segments of the stacked gradient, one launch
+                _wgrad(dqkv, s["h1"], [gbuf(pr.weight) for pr in projs], M, 3 * aw, d, db=[gbuf(pr.bias) for pr in projs])
+            else:   # rows of the padded projections; the q rows were scaled by qfix in the forward
+                tw_, tb_ = zeros(3, aw, d), zeros(3, aw)
+                _wgrad(dqkv, s["h1"], [tw_[0], tw_[1], tw_[2]], M, 3 * aw, d, db=[tb_[0], tb_[1], tb_[2]])
+                for i, proj in enumerate(projs):
                     f = tw.qfix if i == 0 else 1.0
-                    gbuf(proj.weight).view(H, dh, d).add_(tw_.view(H, dhp, d)[:, :dh], alpha=f)
-                    gbuf(proj.bias).view(H, dh).add_(tb_.view(H, dhp)[:, :dh], alpha=f)
+                    gbuf(proj.weight).view(H, dh, d).add_(tw_[i].view(H, dhp, d)[:, :dh], alpha=f)
+                    gbuf(proj.bias).view(H, dh).add_(tb_[i].view(H, dhp)[:, :dh], alpha=f)
             _gemm(dqkv, w["wqkvT"], None, dh_buf, M, d, d, 3 * aw, d, 0)
             _ln_bwd(dh_buf, s["x_in"], s["st1"], blk.norm1.weight, dx, dx, gbuf(blk.norm1.weight), gbuf(blk.norm1.bias), M, d)
         if drop is not None:

@@ -2,6 +2,7 @@
 // weight-gradient GEMM, bias column sums, attention backward, embedding backward, global
 // gradient norm and the fused AdamW update.
 #include "bd_common.h"
+#include <stdlib.h>
 #include "bd_drop.h"
 #include "bidiff.h"
 
@@ -188,7 +189,7 @@ __device__ __forceinline__ s16x4 lds_read_tr(const unsigned char* p) {
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const unsigned short* __restrict__ dY, int ldy,
                                                        const unsigned short* __restrict__ X, int ldx,
                                                        float* __restrict__ dW, int M, int N, int K,
-                                                       int tiles_k, int tokens_per_split) {
+                                                       int tiles_k, int tiles, int tokens_per_split) {
   constexpr int TB = 64 * 256;   // bytes of one 64-token x 128-column tile
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TB];
   unsigned char* const Ys = smem;
@@ -196,8 +197,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const unsigned short* __r
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wk = wave & 1;
   const int g = lane >> 4, c = lane & 15;
-  const int n0 = (blockIdx.x / tiles_k) * 128, k0 = (blockIdx.x % tiles_k) * 128;
-  const int m_begin = blockIdx.y * tokens_per_split;
+  // Workgroups are dealt round-robin to the 8 XCDs (id % 8). All tiles of one token range go to
+  // the SAME XCD, next to each other in time, so that range of dY and X is fetched into that
+  // XCD's L2 once and re-read from there by the other tiles.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tile = slot % tiles, split_id = (slot / tiles) * 8 + xcd;
+  const int n0 = (tile / tiles_k) * 128, k0 = (tile % tiles_k) * 128;
+  const int m_begin = split_id * tokens_per_split;
   int m_end = m_begin + tokens_per_split;
   m_end = m_end < M ? m_end : M;
   if (m_begin >= m_end) return;
@@ -278,6 +284,148 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const unsigned short* __r
 #pragma unroll
       for (int tk = 0; tk < 4; ++tk) atomicAdd(o + 16 * tk, acc[tn][tk][r]);
     }
+}
+
+// -------------------------------------------------------------------------------------
+// The same product with the operand tiles streamed by LDS-DMA through a 4-stage ring (three
+// 32-token steps in flight per workgroup, two workgroups per CU): the register-staged kernel
+// above has one step in flight and is bound by the load latency. Needs M % 32 == 0.
+//  * Output rows may be split into up to three segments with their own destinations (the stacked
+//    q | k | v gradient goes to three parameters in one launch), and the column sums of dY (bias
+//    gradients) come from one extra MFMA per tile against an all-ones operand.
+//  * Work split: XCD x (workgroup id % 8) owns the 32-token chunks q = x (mod 8); inside it the
+//    chunks are dealt to J groups; workgroup (x, tile, j) walks chunks x + 8 (j + J i). All
+//    tiles of a group walk the same chunks at the same time, so a chunk of dY and X enters that
+//    XCD's L2 once. One atomic epilogue per workgroup.
+// -------------------------------------------------------------------------------------
+struct WgradArgs {
+  const unsigned short* dY;
+  const unsigned short* X;
+  float* dW[3];
+  float* db[3];
+  int ldy, ldx, seg_rows;
+  int N, K, tiles_k, tiles, J, n_chunks;
+};
+constexpr int WG_STAGES = 4;
+constexpr int WG_TILE = 32 * 256;        // 32 tokens x 128 bf16 columns
+constexpr int WG_STAGE = 2 * WG_TILE;
+
+typedef __attribute__((address_space(1))) void wg_glb_void;
+typedef __attribute__((address_space(3))) void wg_lds_void;
+
+__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradArgs p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[WG_STAGES * WG_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wk = wave & 1;
+  const int g = lane >> 4, c = lane & 15;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tile = slot % p.tiles, j = slot / p.tiles;
+  const int n0 = (tile / p.tiles_k) * 128, k0 = (tile % p.tiles_k) * 128;
+  const int q0 = xcd + 8 * j, qstride = 8 * p.J;
+  if (q0 >= p.n_chunks) return;
+  const int steps = (p.n_chunks - q0 + qstride - 1) / qstride;
+
+  // LDS-DMA: one wave instruction fills 1 KiB = 4 token rows; lane -> row lane / 16, physical
+  // 16-byte chunk lane % 16, which holds global chunk (lane % 16) ^ swizzle(row). For the rows
+  // 4 f + lane / 16 with f = wave or wave + 4 the swizzle ((row & 3) << 2) | ((row >> 2) & 3) is
+  // ((lane / 16) << 2) | wave: the same for both of the wave's instructions.
+  const int ch = (lane & 15) ^ (((lane >> 4) << 2) | wave);
+  const unsigned short* gy = p.dY + (size_t)(4 * wave + (lane >> 4)) * p.ldy + n0 + ch * 8;
+  const unsigned short* gx = p.X + (size_t)(4 * wave + (lane >> 4)) * p.ldx + k0 + ch * 8;
+  auto issue = [&](int i) {
+    const size_t m0 = (size_t)(q0 + i * qstride) * 32;
+    unsigned char* st = smem + (i % WG_STAGES) * WG_STAGE + wave * 1024;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      __builtin_amdgcn_global_load_lds((wg_glb_void*)(gy + (m0 + 16 * u) * p.ldy), (wg_lds_void*)(st + u * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((wg_glb_void*)(gx + (m0 + 16 * u) * p.ldx), (wg_lds_void*)(st + WG_TILE + u * 4096), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[4][4], accb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const int seg = n0 / p.seg_rows;
+  const bool want_bias = (k0 == 0) && (wk == 0) && p.db[seg] != nullptr;   // wave-uniform
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+#pragma unroll
+  for (int i = 0; i < WG_STAGES - 1; ++i)
+    if (i < steps) issue(i);
+  // LDS reads as inline asm with their own wait: the compiler would make every LDS read wait for
+  // ALL outstanding LDS-DMA loads (it cannot tell the stages apart), which serialises the ring.
+  const int q4 = c >> 2, p4 = c & 3;
+  const int r0 = 8 * g + q4;
+  unsigned ay[4][2], ax[4][2];   // byte offsets inside a stage, then absolute LDS addresses
+  const unsigned lds0 = (unsigned)(size_t)(wg_lds_void*)smem;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int chy = 8 * wn + 2 * t + (p4 >> 1), chx = 8 * wk + 2 * t + (p4 >> 1);
+    ay[t][0] = lds0 + tile_off(r0, chy) + 8 * (p4 & 1);
+    ay[t][1] = lds0 + tile_off(r0 + 4, chy) + 8 * (p4 & 1);
+    ax[t][0] = lds0 + WG_TILE + tile_off(r0, chx) + 8 * (p4 & 1);
+    ax[t][1] = lds0 + WG_TILE + tile_off(r0 + 4, chx) + 8 * (p4 & 1);
+  }
+  for (int st = 0; st < steps; ++st) {
+    const int ahead = steps - 1 - st;          // steps already issued beyond this one (capped at 2)
+    // my part of this stage has landed; after the barrier everybody's has, and everybody has left
+    // the stage of the previous step, which the next issue overwrites
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (st + WG_STAGES - 1 < steps) issue(st + WG_STAGES - 1);
+    const unsigned so = (st % WG_STAGES) * WG_STAGE;
+    union Frag { struct { s16x4 a, b; } s; bf16x8 v; };
+    Frag fy[4], fx[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fy[t].s.a) : "v"(ay[t][0] + so));
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fy[t].s.b) : "v"(ay[t][1] + so));
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fx[t].s.a) : "v"(ax[t][0] + so));
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fx[t].s.b) : "v"(ax[t][1] + so));
+    }
+    // every register written by the reads above passes through the wait before its first use
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(fy[0].v), "+v"(fy[1].v), "+v"(fy[2].v), "+v"(fy[3].v), "+v"(fx[0].v), "+v"(fx[1].v),
+                   "+v"(fx[2].v), "+v"(fx[3].v));
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+      for (int tk = 0; tk < 4; ++tk)
+        acc[tn][tk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[tn].v, fx[tk].v, acc[tn][tk], 0, 0, 0);
+    if (want_bias) {
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) accb[tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[tn].v, ones, accb[tn], 0, 0, 0);
+    }
+  }
+  // lane (g, c): n = n0 + 64 wn + 16 tn + 4 g + r, k = k0 + 64 wk + 16 tk + c
+  float* const dW = p.dW[seg] - (size_t)seg * p.seg_rows * p.K;
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + 64 * wn + 16 * tn + 4 * g + r;
+      float* o = dW + (size_t)n * p.K + k0 + 64 * wk + c;
+#pragma unroll
+      for (int tk = 0; tk < 4; ++tk) atomicAdd(o + 16 * tk, acc[tn][tk][r]);
+    }
+  if (want_bias && c == 0) {   // every column of the ones product holds the same sums
+    float* const db = p.db[seg] - (size_t)seg * p.seg_rows;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(db + n0 + 64 * wn + 16 * tn + 4 * g + r, accb[tn][r]);
+  }
 }
 
 // out[n] += sum_m dY[m, n]   (bias gradients). A workgroup owns 64 columns x up to 512 rows:
@@ -695,22 +843,82 @@ extern "C" int bd_layernorm_bwd(const void* dy_bf16, const float* x, const float
   return bd_check_launch("bd_layernorm_bwd");
 }
 
+// Group count J of the LDS-DMA kernel from a small cost model fitted to measurements (microseconds):
+// an XCD runs its workgroups in rounds of two per CU; a 32-token step takes 0.42 us with one
+// workgroup on the CU (load latency with three steps in flight) up to 0.6 us with two; the atomic
+// epilogues of all 8 J token groups drain at the L2 rate of one fp32 add per clock and channel,
+// ~0.35 M per microsecond.
+static int wgrad_groups(int tiles, int n_chunks, long long out_elems, int cus_per_xcd) {
+  int best = 1;
+  double best_t = 1e30;
+  const int per_xcd = (n_chunks + 7) / 8;
+  for (int J = 1; J <= 16 && J <= per_xcd; ++J) {
+    const int wgs = tiles * J;
+    const int rounds = (wgs + 2 * cus_per_xcd - 1) / (2 * cus_per_xcd);
+    double w = (double)wgs / cus_per_xcd / rounds;
+    w = w < 1.0 ? 1.0 : w;
+    const double step_us = 0.42 + 0.18 * (w - 1.0);
+    const double t = rounds * ((per_xcd + J - 1) / J) * step_us + 8.0 * J * (double)out_elems / 0.35e6;
+    if (t < best_t) { best_t = t; best = J; }
+  }
+  return best;
+}
+
+extern "C" int bd_gemm_wgrad_segments(const void* dY, int ldy, const void* X, int ldx, float* const* dW,
+                                      float* const* db, int n_seg, int seg_rows, int M, int K, void* stream) {
+  BD_REQUIRE(dY && X && dW, "bd_gemm_wgrad: null operand");
+  BD_REQUIRE(n_seg >= 1 && n_seg <= 3, "bd_gemm_wgrad: %d segments (1..3)", n_seg);
+  const int N = n_seg * seg_rows;
+  BD_REQUIRE(M > 0 && seg_rows > 0 && K > 0 && seg_rows % 128 == 0 && K % 128 == 0,
+             "bd_gemm_wgrad: rows=%d and K=%d must be multiples of 128", seg_rows, K);
+  BD_REQUIRE(ldy >= N && ldx >= K && ldy % 8 == 0 && ldx % 8 == 0, "bd_gemm_wgrad: bad leading dimension");
+  for (int i = 0; i < n_seg; ++i) BD_REQUIRE(dW[i] != nullptr, "bd_gemm_wgrad: null destination %d", i);
+  hipStream_t s = (hipStream_t)stream;
+  static int use_dma = getenv("BD_WGRAD_DMA") ? atoi(getenv("BD_WGRAD_DMA")) : 1;
+  if (M % 32 == 0 && use_dma) {
+    static int ncu = 0;
+    if (!ncu) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+      else ncu = 256;
+    }
+    WgradArgs a{};
+    a.dY = (const unsigned short*)dY; a.X = (const unsigned short*)X;
+    for (int i = 0; i < n_seg; ++i) { a.dW[i] = dW[i]; a.db[i] = db ? db[i] : nullptr; }
+    a.ldy = ldy; a.ldx = ldx; a.seg_rows = seg_rows; a.N = N; a.K = K;
+    a.tiles_k = K / 128; a.tiles = (N / 128) * a.tiles_k; a.n_chunks = M / 32;
+    static int forced = getenv("BD_WGRAD_J") ? atoi(getenv("BD_WGRAD_J")) : 0;
+    a.J = forced > 0 ? forced : wgrad_groups(a.tiles, a.n_chunks, (long long)N * K, ncu / 8 > 0 ? ncu / 8 : 1);
+    const long long grid = 8ll * a.tiles * a.J;
+    BD_REQUIRE(grid < (1ll << 31), "bd_gemm_wgrad: too many tiles");
+    hipLaunchKernelGGL(wgrad_dma_kernel, dim3((unsigned)grid), dim3(256), 0, s, a);
+    return bd_check_launch("bd_gemm_wgrad");
+  }
+  // ragged token count: the register-staged kernel, one segment at a time, bias sums separately
+  for (int i = 0; i < n_seg; ++i) {
+    const unsigned short* y = (const unsigned short*)dY + (size_t)i * seg_rows;
+    const int tiles_k = K / 128, tiles = (seg_rows / 128) * tiles_k;
+    int split = (1024 + tiles - 1) / tiles;
+    const int max_split = (M + 511) / 512;   // at least 8 token steps per workgroup
+    split = split > max_split ? max_split : split;
+    split = split < 1 ? 1 : split;
+    int per = ((M + split - 1) / split + 63) / 64 * 64;
+    split = (M + per - 1) / per;
+    const int split8 = (split + 7) / 8 * 8;   // split ids past the last one find an empty token range and leave
+    hipLaunchKernelGGL(wgrad_kernel, dim3(tiles * split8), dim3(256), 0, s, y, ldy, (const unsigned short*)X, ldx, dW[i],
+                       M, seg_rows, K, tiles_k, tiles, per);
+    if (db && db[i])
+      hipLaunchKernelGGL(colsum_kernel, dim3((seg_rows + 63) / 64, (M + CS_ROWS - 1) / CS_ROWS), dim3(256), 0, s, y, ldy,
+                         db[i], M, seg_rows);
+  }
+  return bd_check_launch("bd_gemm_wgrad");
+}
+
 extern "C" int bd_gemm_wgrad_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, int M, int N, int K,
                                   void* stream) {
-  BD_REQUIRE(dY && X && dW, "bd_gemm_wgrad_bf16: null operand");
-  BD_REQUIRE(M > 0 && N > 0 && K > 0 && N % 128 == 0 && K % 128 == 0,
-             "bd_gemm_wgrad_bf16: N=%d and K=%d must be multiples of 128", N, K);
-  BD_REQUIRE(ldy >= N && ldx >= K && ldy % 8 == 0 && ldx % 8 == 0, "bd_gemm_wgrad_bf16: bad leading dimension");
-  const int tiles_k = K / 128, tiles = (N / 128) * tiles_k;
-  int split = (1024 + tiles - 1) / tiles;
-  const int max_split = (M + 511) / 512;   // at least 8 token steps per workgroup
-  split = split > max_split ? max_split : split;
-  split = split < 1 ? 1 : split;
-  int per = ((M + split - 1) / split + 63) / 64 * 64;
-  split = (M + per - 1) / per;
-  hipLaunchKernelGGL(wgrad_kernel, dim3(tiles, split), dim3(256), 0, (hipStream_t)stream,
-                     (const unsigned short*)dY, ldy, (const unsigned short*)X, ldx, dW, M, N, K, tiles_k, per);
-  return bd_check_launch("bd_gemm_wgrad_bf16");
+  BD_REQUIRE(N > 0 && N % 128 == 0, "bd_gemm_wgrad_bf16: N=%d must be a multiple of 128", N);
+  return bd_gemm_wgrad_segments(dY, ldy, X, ldx, &dW, nullptr, 1, N, M, K, stream);
 }
 
 extern "C" int bd_colsum_bf16(const void* dY, int ld, float* out, int M, int N, void* stream) {

@@ -267,6 +267,13 @@ int bd_layernorm_bwd(const void* dy_bf16, const float* x, const float* stats, co
 int bd_gemm_wgrad_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, int M, int N, int K,
                        void* stream);
 
+/* The same for up to three row segments of dY at once, each with its own destination:
+ * dW[s][seg_rows, K] += dY[:, s*seg_rows : (s+1)*seg_rows]^T * X, and, where db and db[s] are given,
+ * db[s][seg_rows] += column sums of that slice (the bias gradient). One launch for the stacked
+ * q | k | v gradient of src/model/backbone.py:25-27. dW / db are host arrays of device pointers. */
+int bd_gemm_wgrad_segments(const void* dY, int ldy, const void* X, int ldx, float* const* dW,
+                           float* const* db, int n_seg, int seg_rows, int M, int K, void* stream);
+
 /* out[n] += sum_m dY[m,n] (bias gradients). */
 int bd_colsum_bf16(const void* dY, int ld, float* out, int M, int N, void* stream);
 

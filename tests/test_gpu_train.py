@@ -104,9 +104,49 @@ def test_wgrad_and_colsum(gpu_device, M, N, K):
     assert rel(bs, dY.float().sum(0) + 1) < 1e-5
 
 
-def test_wgrad_exact_integers(gpu_device):
+@pytest.mark.parametrize("M,seg,nseg,K,extra", [(4096, 384, 3, 384, 0), (32768, 384, 3, 384, 0), (32768, 1536, 1, 384, 0),
+                                                 (640, 128, 2, 1536, 64), (96, 256, 3, 128, 0), (70, 128, 3, 256, 8),
+                                                 (32, 128, 1, 128, 0)])
+def test_wgrad_segments_with_fused_bias_sums(gpu_device, M, seg, nseg, K, extra):
+    """One launch for up to three row segments with separate destinations plus the bias gradients;
+    token counts that are multiples of 32 take the LDS-DMA kernel, others the register-staged one;
+    `extra` = unused columns to the right of the stacked gradient (leading dimension > N)."""
+    import ctypes as C
     dev = gpu_device
-    M, N, K = 200, 256, 128
+    N = seg * nseg
+    g = torch.Generator().manual_seed(M + N + K)
+    dYf = torch.randn(M, N + extra, generator=g).to(dev).bfloat16()
+    X = torch.randn(M, K, generator=g).to(dev).bfloat16()
+    dWs = [torch.full((seg, K), float(i), device=dev) for i in range(nseg)]     # accumulate on top
+    dbs = [torch.full((seg,), float(-i), device=dev) for i in range(nseg)]
+    pw = (C.c_void_p * nseg)(*[t.data_ptr() for t in dWs])
+    pb = (C.c_void_p * nseg)(*[t.data_ptr() for t in dbs])
+    if nseg == 2:           # a missing bias destination is allowed per segment
+        pb[1] = None
+    _lib.check(_lib.lib().bd_gemm_wgrad_segments(_lib.ptr(dYf), N + extra, _lib.ptr(X), K, pw, pb, nseg, seg, M, K, _s()),
+               "wgrad")
+    torch.cuda.synchronize()
+    ref = dYf[:, :N].float().t() @ X.float()
+    cs = dYf[:, :N].float().sum(0)
+    for i in range(nseg):
+        assert rel(dWs[i], ref[i * seg:(i + 1) * seg] + i) < 1e-5, i
+        if nseg == 2 and i == 1:
+            assert torch.equal(dbs[i], torch.full((seg,), float(-i), device=dev))
+        else:
+            assert rel(dbs[i], cs[i * seg:(i + 1) * seg] - i) < 1e-5, i
+    # without any bias destination
+    dW2 = [torch.zeros(seg, K, device=dev) for _ in range(nseg)]
+    pw2 = (C.c_void_p * nseg)(*[t.data_ptr() for t in dW2])
+    _lib.check(_lib.lib().bd_gemm_wgrad_segments(_lib.ptr(dYf), N + extra, _lib.ptr(X), K, pw2, None, nseg, seg, M, K, _s()),
+               "wgrad")
+    for i in range(nseg):
+        assert rel(dW2[i], ref[i * seg:(i + 1) * seg]) < 1e-5
+
+
+@pytest.mark.parametrize("M", [200, 256])
+def test_wgrad_exact_integers(gpu_device, M):
+    dev = gpu_device
+    N, K = 256, 128
     g = torch.Generator().manual_seed(0)
     dY = torch.randint(-3, 4, (M, N), generator=g).float()
     X = torch.randint(-3, 4, (M, K), generator=g).float()
