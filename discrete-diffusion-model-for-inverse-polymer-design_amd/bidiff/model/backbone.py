@@ -350,21 +350,24 @@ class DiffusionBackbone(nn.Module):
         return hidden.float()
 
     def get_pooled_output(self, input_ids, timesteps, attention_mask=None, pooling: str = "mean"):
-        """Masked mean / cls / max pooling of the final hidden states (reference :301-335)."""
-        hs = self.get_hidden_states(input_ids, timesteps, attention_mask)
-        if pooling == "mean":
-            if attention_mask is not None:
-                m = attention_mask.unsqueeze(-1).float()
-                return (hs * m).sum(dim=1) / m.sum(dim=1).clamp(min=1e-9)
-            return hs.mean(dim=1)
-        if pooling == "cls":
-            return hs[:, 0]
-        if pooling == "max":
-            if attention_mask is not None:
-                m = attention_mask.unsqueeze(-1).float()
-                hs = hs * m + (1 - m) * (-1e9)
-            return hs.max(dim=1)[0]
-        raise ValueError(f"Unknown pooling method: {pooling}")
+        """Masked mean / cls / max pooling of the final hidden states, [batch, hidden] fp32 (reference
+        backbone.py:301-335). One pooling kernel over the bf16 hidden rows the forward wrote; no
+        gradient flows through it (the backbone is a frozen feature extractor here)."""
+        modes = {"mean": 0, "cls": 1, "max": 2}
+        if pooling not in modes:
+            raise ValueError(f"Unknown pooling method: {pooling}")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("bidiff: get_pooled_output does not backpropagate into the backbone; freeze "
+                                      "it (requires_grad_(False)) or call under torch.no_grad()")
+        keymask = self._keymask_bytes(attention_mask, input_ids)
+        hidden, _ = self.run_forward(input_ids, timesteps, keymask, want_hidden=True, want_logits=False)
+        B, L = input_ids.shape
+        am = None if attention_mask is None else attention_mask.to(torch.long).contiguous()
+        out = torch.empty(B, self.hidden_size, dtype=torch.float32, device=input_ids.device)
+        rc = _lib.lib().bd_pool_hidden(_lib.ptr(hidden), _lib.ptr(am), _lib.ptr(out), B, L, self.hidden_size,
+                                       modes[pooling], _lib.stream_handle())
+        _lib.check(rc, "bd_pool_hidden")
+        return out
 
     def config_dict(self):
         return {

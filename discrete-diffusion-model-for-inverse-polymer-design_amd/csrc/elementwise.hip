@@ -39,6 +39,64 @@ __global__ __launch_bounds__(256) void embed_kernel(const long long* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------
+// Pooling of the final hidden states over the sequence: [B, L, d] bf16 -> [B, d] fp32.
+//   mean: sum_l h * m / max(sum_l m, 1e-9)   (plain mean without a mask)
+//   max : max_l (h * m + (1 - m) * -1e9)     (plain max without a mask)
+//   cls : h[:, 0]
+// m = float(attention_mask). A workgroup owns (sequence, 512 columns): lane = 8 columns
+// (one 16-byte load per row), the four waves take rows 4 apart and meet in LDS.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool_kernel(const unsigned short* __restrict__ h,
+                                                   const long long* __restrict__ mask, float* __restrict__ out,
+                                                   int L, int d, int mode) {
+  __shared__ float red[4][512];
+  __shared__ float msum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x, col = blockIdx.y * 512 + lane * 8;
+  const bool on = col < d;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = mode == 2 ? -INFINITY : 0.f;
+  float ms = 0.f;
+  const int l_end = mode == 1 ? 1 : L;
+  for (int l = wave; l < l_end; l += 4) {
+    const float m = mask ? (float)mask[(size_t)b * L + l] : 1.0f;
+    ms += m;
+    if (!on) continue;
+    const u32x4 w = *(const u32x4*)(h + ((size_t)b * L + l) * d + col);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+      if (mode == 2) {
+        const float fill = (1.0f - m) * -1e9f;
+        acc[2 * e] = fmaxf(acc[2 * e], mask ? lo * m + fill : lo);
+        acc[2 * e + 1] = fmaxf(acc[2 * e + 1], mask ? hi * m + fill : hi);
+      } else {
+        acc[2 * e] += lo * m;
+        acc[2 * e + 1] += hi * m;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[wave][lane * 8 + e] = acc[e];
+  if (lane == 0) msum[wave] = ms;
+  __syncthreads();
+  // thread t finishes columns t and t + 256 of the slab
+  for (int cc = threadIdx.x; cc < 512; cc += 256) {
+    const int c2 = blockIdx.y * 512 + cc;
+    if (c2 >= d) continue;
+    float v;
+    if (mode == 2) v = fmaxf(fmaxf(red[0][cc], red[1][cc]), fmaxf(red[2][cc], red[3][cc]));
+    else v = (red[0][cc] + red[1][cc]) + (red[2][cc] + red[3][cc]);
+    if (mode == 0) {
+      const float cnt = mask ? (msum[0] + msum[1]) + (msum[2] + msum[3]) : (float)L;
+      v = v / fmaxf(cnt, 1e-9f);
+    }
+    out[(size_t)b * d + c2] = v;
+  }
+}
+
 // out[m, n] = x[m, n] * keep / (1 - p), fp32 or bf16 result; one thread per four columns
 template <bool BF16_OUT>
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, void* __restrict__ out,
@@ -160,6 +218,16 @@ __global__ __launch_bounds__(256) void mask_to_bytes_kernel(const long long* __r
 extern "C" int bd_embed(const long long* ids, const long long* timesteps, const float* tok_emb,
                         const float* pos_emb, const float* time_emb, float* x, int B, int L, int d, void* stream) {
   return bd_embed_drop(ids, timesteps, tok_emb, pos_emb, time_emb, x, B, L, d, nullptr, 0u, stream);
+}
+
+extern "C" int bd_pool_hidden(const void* hidden_bf16, const long long* attention_mask, float* out, int B, int L,
+                              int d, int mode, void* stream) {
+  BD_REQUIRE(hidden_bf16 && out, "bd_pool_hidden: null operand");
+  BD_REQUIRE(B > 0 && L > 0 && d > 0 && d % 8 == 0 && B <= 2147483647, "bd_pool_hidden: bad shape B=%d L=%d d=%d", B, L, d);
+  BD_REQUIRE(mode >= 0 && mode <= 2, "bd_pool_hidden: unknown pooling mode %d (0 mean, 1 cls, 2 max)", mode);
+  hipLaunchKernelGGL(pool_kernel, dim3(B, (d + 511) / 512), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)hidden_bf16, mode == 1 ? nullptr : attention_mask, out, L, d, mode);
+  return bd_check_launch("bd_pool_hidden");
 }
 
 static int dropout_launch(const float* x, void* out, int M, int N, const bd_dropout* drop, unsigned site, bool bf16,

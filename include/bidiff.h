@@ -186,6 +186,13 @@ int bd_backbone_forward_layers(const bd_backbone_desc* desc, const long long* id
                                void* workspace, long long workspace_bytes, int n_run, float* resid_out,
                                void* stream);
 
+/* Pooling of the final hidden states over the sequence: hidden [B, L, d] bf16 -> out [B, d] fp32.
+ * mode 0 = mean: sum(h * m) / max(sum m, 1e-9) with m = float(attention_mask) (plain mean when the
+ * mask is null); 1 = cls: h[:, 0]; 2 = max over h * m + (1 - m) * -1e9 (plain max without a mask).
+ * replaces DiffusionBackbone.get_pooled_output, src/model/backbone.py:301-335. */
+int bd_pool_hidden(const void* hidden_bf16, const long long* attention_mask, float* out, int B, int L,
+                   int d, int mode, void* stream);
+
 /* bd_gemm_bf16 with the extra operands some epilogues take:
  *   epilogue 1: aux_out (optional) receives the bf16 pre-activation acc + bias (saved for backward)
  *   epilogue 2: aux_in (optional) is the fp32 residual input; out = aux_in + acc + bias

@@ -84,6 +84,36 @@ def hidden_states(sd, cfg, input_ids, timesteps, attention_mask=None, prefix="",
     return F.layer_norm(x, (d,), sd[p + "final_norm.weight"], sd[p + "final_norm.bias"], eps)
 
 
+def pooled_output(sd, cfg, input_ids, timesteps, attention_mask=None, pooling="mean", prefix=""):
+    """Masked mean / cls / max pooling of the final hidden states (reference backbone.py:301-335)."""
+    hs = hidden_states(sd, cfg, input_ids, timesteps, attention_mask, prefix)
+    if pooling == "mean":
+        if attention_mask is None:
+            return hs.mean(dim=1)
+        m = attention_mask.unsqueeze(-1).float()
+        return (hs * m).sum(dim=1) / m.sum(dim=1).clamp(min=1e-9)
+    if pooling == "cls":
+        return hs[:, 0]
+    if pooling == "max":
+        if attention_mask is not None:
+            m = attention_mask.unsqueeze(-1).float()
+            hs = hs * m + (1 - m) * (-1e9)
+        return hs.max(dim=1)[0]
+    raise ValueError(f"Unknown pooling method: {pooling}")
+
+
+def property_head(head_sd, pooled):
+    """The regression MLP in eval mode: Linear -> ReLU per hidden layer, then Linear(., 1)
+    (reference property_head.py:32-47,60-69; state_dict keys ``mlp.<3 i>.weight/bias``)."""
+    n = len([k for k in head_sd if k.endswith(".weight")])
+    x = pooled
+    for i in range(n):
+        x = F.linear(x, head_sd[f"mlp.{3 * i}.weight"], head_sd[f"mlp.{3 * i}.bias"])
+        if i < n - 1:
+            x = F.relu(x)
+    return x
+
+
 def logits(sd, cfg, input_ids, timesteps, attention_mask=None, prefix="", dropout=None):
     h = hidden_states(sd, cfg, input_ids, timesteps, attention_mask, prefix, dropout=dropout)
     return F.linear(h, sd[prefix + "output_proj.weight"])

@@ -136,6 +136,9 @@ SMALL_CFG = dict(vocab_size=39, hidden_size=384, num_layers=6, num_heads=3, ffn_
                  max_position_embeddings=256, num_diffusion_steps=100, dropout=0.1, pad_token_id=0)
 
 
+PROPERTY_HIDDEN = [256, 64]      # the reference default of PropertyHead (property_head.py:17)
+
+
 def perturb_state_dict(sd, seed):
     """Make biases and LayerNorm affine parameters non-trivial (the seeded init leaves them at
     0 / 1): in-place, key order of the state_dict, frozen RandomState stream."""
