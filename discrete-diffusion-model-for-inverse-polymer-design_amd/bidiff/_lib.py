@@ -116,6 +116,11 @@ SIGNATURES = {
     "bd_layernorm_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, VP]),
     "bd_gemm_wgrad_bf16": (C.c_int, [VP, C.c_int, VP, C.c_int, VP, C.c_int, C.c_int, C.c_int, VP]),
     "bd_gemm_wgrad_segments": (C.c_int, [VP, C.c_int, VP, C.c_int, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
+    "bd_gemm_bf16_batched": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong, C.c_int, C.c_int,
+                                       C.c_int, C.c_float, C.c_float, VP]),
+    "bd_muon_workspace_bytes": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
+    "bd_muon_step": (C.c_int, [VP, VP, VP, VP, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                               C.c_int, C.c_int, VP, C.c_float, VP]),
     "bd_colsum_bf16": (C.c_int, [VP, C.c_int, VP, C.c_int, C.c_int, VP]),
     "bd_attention_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "bd_embed_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),

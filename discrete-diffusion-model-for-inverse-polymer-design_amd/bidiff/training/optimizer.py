@@ -97,3 +97,146 @@ class FlatAdamW(torch.optim.Optimizer):
             for k in ("lr", "betas", "eps", "weight_decay", "initial_lr"):
                 if k in g_old:
                     g_new[k] = g_old[k]
+
+
+class FlatMuonAdamW(torch.optim.Optimizer):
+    """Mixed Muon / AdamW optimizer over one flat fp32 buffer: drop-in for ``MuonAdamW(param_groups)``
+    (shared/optimizer_setup.py:70-169). ``params`` is the reference's list of group dicts with
+    ``kind`` in {"adamw", "muon"}. Flat layout: all AdamW parameters first (one fused bd_adamw_step
+    over that range), then the Muon matrices grouped by shape, each shape class back to back so that
+    one bd_muon_step (momentum, Newton-Schulz on batched bf16 MFMA GEMMs, update) handles the class.
+    The flat gradient buffer is the data-parallel all-reduce bucket, as in FlatAdamW; ``state_dict``
+    keeps the reference's per-parameter keys (``step`` / ``exp_avg`` / ``exp_avg_sq`` or
+    ``momentum_buffer``), the tensors being views into the flat buffers."""
+
+    def __init__(self, params):
+        defaults = dict(lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.0, kind="adamw", momentum=0.95,
+                        nesterov=True, backend_steps=5)
+        super().__init__(params, defaults)
+        adamw, muon = [], []
+        for g in self.param_groups:
+            kind = g.get("kind", "adamw")
+            if kind not in {"adamw", "muon"}:
+                raise ValueError(f"Unsupported optimizer group kind: {kind}")
+            for p in g["params"]:
+                if not p.requires_grad:
+                    continue
+                if kind == "muon":
+                    if p.ndim != 2:
+                        raise RuntimeError(f"Muon path only supports 2D tensors, got shape {tuple(p.shape)}")
+                    if p.shape[0] % 128 or p.shape[1] % 128:
+                        raise NotImplementedError(f"bidiff Muon kernels need matrix sizes that are multiples of 128, "
+                                                  f"got {tuple(p.shape)}")
+                    muon.append((p, g))
+                else:
+                    adamw.append((p, g))
+        if not adamw and not muon:
+            raise ValueError("FlatMuonAdamW: no trainable parameters")
+        if len({id(g) for _, g in adamw}) > 1 or len({id(g) for _, g in muon}) > 1:
+            raise NotImplementedError("FlatMuonAdamW: one adamw group and one muon group, as the reference builds them")
+        self._adamw_group = adamw[0][1] if adamw else None
+        self._muon_group = muon[0][1] if muon else None
+        classes = {}
+        for p, _ in muon:
+            classes.setdefault(tuple(p.shape), []).append(p)
+        order = [p for p, _ in adamw] + [p for ps in classes.values() for p in ps]
+        dev = order[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FlatMuonAdamW: parameters must live on a ROCm device (no CPU path)")
+        self.n_adamw = sum(p.numel() for p, _ in adamw)
+        self.numel = n = sum(p.numel() for p in order)
+        self.flat_param = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)      # exp_avg | momentum buffers
+        self.flat_v = torch.zeros(max(self.n_adamw, 1), dtype=torch.float32, device=dev)
+        self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._step = 0
+        self._params, self._offsets = order, []
+        off = 0
+        with torch.no_grad():
+            for i, p in enumerate(order):
+                k = p.numel()
+                self.flat_param[off:off + k].copy_(p.detach().reshape(-1))
+                p.data = self.flat_param[off:off + k].view(p.shape)
+                p.grad = self.flat_grad[off:off + k].view(p.shape)
+                if off < self.n_adamw:
+                    self.state[p] = {"step": 0, "exp_avg": self.flat_m[off:off + k].view(p.shape),
+                                     "exp_avg_sq": self.flat_v[off:off + k].view(p.shape)}
+                else:
+                    self.state[p] = {"momentum_buffer": self.flat_m[off:off + k].view(p.shape)}
+                self._offsets.append(off)
+                off += k
+        self._classes = []          # (flat offset, count, rows, cols)
+        off = self.n_adamw
+        ws = 0
+        for (rows, cols), ps in classes.items():
+            self._classes.append((off, len(ps), rows, cols))
+            ws = max(ws, int(_lib.lib().bd_muon_workspace_bytes(len(ps), rows, cols)))
+            off += len(ps) * rows * cols
+        self._ws = torch.empty(max(ws, 1), dtype=torch.uint8, device=dev)
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.flat_grad.zero_()
+        for p, off in zip(self._params, self._offsets):       # keep .grad bound to the flat buffer
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
+                p.grad = self.flat_grad[off:off + p.numel()].view(p.shape)
+
+    def grad_norm(self):
+        self._sumsq.zero_()
+        _lib.check(_lib.lib().bd_sumsq_f32(_lib.ptr(self.flat_grad), self.numel, _lib.ptr(self._sumsq),
+                                           _lib.stream_handle()), "bd_sumsq_f32")
+        return self._sumsq.sqrt()
+
+    @torch.no_grad()
+    def step(self, closure=None, max_norm: float = 0.0):
+        """One update of both groups; ``max_norm > 0`` first clips the global gradient norm (all
+        parameters of both groups) to it."""
+        lib, s = _lib.lib(), _lib.stream_handle()
+        self._step += 1
+        ss = None
+        if max_norm and max_norm > 0:
+            self._sumsq.zero_()
+            _lib.check(lib.bd_sumsq_f32(_lib.ptr(self.flat_grad), self.numel, _lib.ptr(self._sumsq), s), "bd_sumsq_f32")
+            ss = self._sumsq
+        if self.n_adamw:
+            g = self._adamw_group
+            b1, b2 = g.get("betas", (0.9, 0.95))
+            bc1 = 1.0 - b1 ** self._step
+            bc2_sqrt = math.sqrt(1.0 - b2 ** self._step)
+            _lib.check(lib.bd_adamw_step(_lib.ptr(self.flat_param), _lib.ptr(self.flat_grad), _lib.ptr(self.flat_m),
+                                         _lib.ptr(self.flat_v), self.n_adamw, float(g["lr"]), float(b1), float(b2),
+                                         float(g.get("eps", 1e-8)), float(g.get("weight_decay", 0.0)), float(bc1),
+                                         float(bc2_sqrt), _lib.ptr(ss), float(max_norm or 0.0), s), "bd_adamw_step")
+        if self._classes:
+            g = self._muon_group
+            for off, nb, rows, cols in self._classes:
+                _lib.check(lib.bd_muon_step(_lib.ptr(self.flat_param[off:]), _lib.ptr(self.flat_grad[off:]),
+                                            _lib.ptr(self.flat_m[off:]), _lib.ptr(self._ws), self._ws.numel(), nb, rows, cols,
+                                            float(g["lr"]), float(g.get("weight_decay", 0.0)),
+                                            float(g.get("momentum", 0.95)), int(bool(g.get("nesterov", True))),
+                                            int(g.get("backend_steps", 5)), _lib.ptr(ss), float(max_norm or 0.0), s),
+                           "bd_muon_step")
+        for p in self._params:
+            if "step" in self.state[p]:
+                self.state[p]["step"] = self._step
+        _lib.bump_weights_generation()
+        return None
+
+    def load_state_dict(self, state_dict):
+        sd = state_dict["state"]
+        idx = 0
+        for g in self.param_groups:
+            for p in g["params"]:
+                st = sd.get(idx)
+                idx += 1
+                if st is None or p not in self.state:
+                    continue
+                for k in ("exp_avg", "exp_avg_sq", "momentum_buffer"):
+                    if k in st and k in self.state[p]:
+                        self.state[p][k].copy_(st[k])
+                if "step" in st:
+                    self._step = int(float(st["step"]))
+        for g_new, g_old in zip(self.param_groups, state_dict["param_groups"]):
+            for k in ("lr", "betas", "eps", "weight_decay", "initial_lr", "momentum", "nesterov", "backend_steps"):
+                if k in g_old:
+                    g_new[k] = g_old[k]

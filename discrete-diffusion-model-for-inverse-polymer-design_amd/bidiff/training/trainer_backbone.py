@@ -20,7 +20,8 @@ import torch
 import torch.distributed as dist
 from torch.optim.lr_scheduler import CosineAnnealingLR, LinearLR, SequentialLR
 
-from .optimizer import FlatAdamW
+from .optimizer import FlatAdamW  # noqa: F401
+from .optimizer_setup import build_step1_backbone_optimizer
 from ..parallel import allreduce_mean_
 
 
@@ -67,13 +68,16 @@ class BackboneTrainer:
         self.save_best_only = ck.get("save_best_only", True)
         self.save_last = ck.get("save_last", False)
         self.save_periodic = ck.get("save_periodic", False)
-        if bool(opt.get("use_muon", False)) or str(opt.get("optimizer", "adamw")).lower().startswith("muon"):
-            raise NotImplementedError("bidiff: the Muon optimizer branch is not built; use AdamW")
-
         if self.distributed:   # same start on every rank, as DDP's construction broadcast does
             for t in list(self.model.parameters()) + list(self.model.buffers()):
                 dist.broadcast(t.data, src=0)
-        self.optimizer = FlatAdamW(self.model.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay)
+        # AdamW or Muon + AdamW groups, driven by config["optimization"]["optimizer"] as in the reference
+        # (trainer_backbone.py:164-178)
+        self.optimizer, info = build_step1_backbone_optimizer(self.model, opt, self.learning_rate, self.weight_decay)
+        if self.is_main_process and info.get("type") == "muon_adamw":
+            print("Using Muon+AdamW optimizer groups: "
+                  f"muon_tensors={info.get('num_muon_tensors')}, adamw_tensors={info.get('num_adamw_tensors')}, "
+                  f"adamw_lr={info.get('adamw_lr'):.3e}, muon_lr={info.get('muon_lr'):.3e}")
         warm = LinearLR(self.optimizer, start_factor=0.01, end_factor=1.0, total_iters=max(1, self.warmup_steps))
         cos = CosineAnnealingLR(self.optimizer, T_max=max(1, self.max_steps - self.warmup_steps), eta_min=1e-6)
         self.scheduler = SequentialLR(self.optimizer, schedulers=[warm, cos], milestones=[self.warmup_steps])

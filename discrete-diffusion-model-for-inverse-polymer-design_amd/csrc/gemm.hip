@@ -23,7 +23,9 @@ enum Epi : int {
   EPI_BIAS_GELU_BF16 = 1,  // out bf16 = gelu(acc + bias)   (erf form, F.gelu default)
   EPI_BIAS_RESID_F32 = 2,  // out fp32 += acc + bias        (residual stream, in place)
   EPI_F32 = 3,             // out fp32 = acc (+ bias if given), columns >= n_real dropped
-  EPI_DGELU_BF16 = 4       // out bf16 = (acc + bias) * gelu'(aux)   (aux = pre-activation, bf16)
+  EPI_DGELU_BF16 = 4,      // out bf16 = (acc + bias) * gelu'(aux)   (aux = pre-activation, bf16)
+  EPI_AXPBY_BF16 = 5       // out bf16 = rn(rn(beta * aux) + rn(alpha * rn(acc))), aux bf16 laid out like out; every
+                           // product and the sum rounded to bf16 as a chain of bf16 tensor ops would
 };
 
 struct GemmArgs {
@@ -36,6 +38,8 @@ struct GemmArgs {
   int M, Npad, K, n_real, ldc;
   int tiles_n, n_tiles;
   bd_drop_args drop;         // DROP kernels: dropout of the epilogue value at (row m, column n)
+  long long sA, sW, sOut;    // batched launch (gridDim.y problems): element strides of A, W and out / aux_in
+  float alpha, beta;         // EPI 5
 };
 
 __device__ __forceinline__ int swz_a(int row) { return row & 7; }
@@ -81,6 +85,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int g = lane >> 4, c = lane & 15;
+  if (EPI == EPI_AXPBY_BF16 || EPI == EPI_BIAS_BF16) {   // the epilogues batched launches use
+    const long long b = blockIdx.y;
+    p.A += b * p.sA;
+    p.W += b * p.sW;
+    p.out = (unsigned short*)p.out + b * p.sOut;
+    if (EPI == EPI_AXPBY_BF16) p.aux_in = (const unsigned short*)p.aux_in + b * p.sOut;
+  }
 
   // XCD-aware, bijective remap: blocks that share an XCD (id % 8) walk a contiguous
   // run of tiles (n fastest), so the A row-panel is re-read from that XCD's L2.
@@ -203,7 +214,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[4 * tn + r] = acc[tn][tm][r] + bv[4 * tn + r];
-    if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_DGELU_BF16) {
+    if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_DGELU_BF16 || EPI == EPI_AXPBY_BF16) {
+      if (EPI == EPI_AXPBY_BF16) {
+        const unsigned short* xi = (const unsigned short*)p.aux_in + (size_t)m * p.ldc + nb;
+        const u32x4 lo = *(const u32x4*)(xi), hi = *(const u32x4*)(xi + 8);
+        float x[16];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          x[2 * e] = __uint_as_float(lo[e] << 16);     x[2 * e + 1] = __uint_as_float(lo[e] & 0xffff0000u);
+          x[8 + 2 * e] = __uint_as_float(hi[e] << 16); x[8 + 2 * e + 1] = __uint_as_float(hi[e] & 0xffff0000u);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const float prod = bd_bf16_to_f32(bd_f32_to_bf16(v[j]));
+          v[j] = bd_bf16_to_f32(bd_f32_to_bf16(p.beta * x[j])) + bd_bf16_to_f32(bd_f32_to_bf16(p.alpha * prod));
+        }
+      }
       if (EPI == EPI_BIAS_GELU_BF16) {
         if (p.aux_out != nullptr) {
           unsigned short* uo = (unsigned short*)p.aux_out + (size_t)m * p.ldc + nb;
@@ -296,6 +322,7 @@ extern "C" int bd_gemm_bf16_drop(const void* A, const void* W, const float* bias
   a.aux_in = aux_in; a.aux_out = aux_out;
   BD_REQUIRE(epilogue != EPI_DGELU_BF16 || aux_in != nullptr, "bd_gemm_bf16: epilogue 4 needs the pre-activation");
   a.M = M; a.Npad = n_pad; a.K = K; a.n_real = n_real; a.ldc = ldc;
+  a.sA = a.sW = a.sOut = 0; a.alpha = 1.f; a.beta = 0.f;
   a.tiles_n = n_pad / BN;
   const long long tiles_m = ((long long)M + BM - 1) / BM;
   const long long nt = tiles_m * a.tiles_n;
@@ -319,6 +346,36 @@ extern "C" int bd_gemm_bf16_drop(const void* A, const void* W, const float* bias
     case EPI_DGELU_BF16: return launch<EPI_DGELU_BF16>(a, s);
     default: return bd_fail(BD_ERR_ARG, "bd_gemm_bf16: unknown epilogue %d", epilogue);
   }
+}
+
+// Batched C_b = A_b W_b^T over `batch` problems of one shape (element strides sA, sW, sOut; a zero
+// stride shares the operand), bf16 out with row stride N. aux == null: out = acc. aux given (bf16,
+// laid out like out): out = rn(rn(beta * aux) + rn(alpha * rn(acc))).
+extern "C" int bd_gemm_bf16_batched(const void* A, const void* W, void* out, const void* aux, int batch,
+                                    long long sA, long long sW, long long sOut, int M, int N, int K, float alpha,
+                                    float beta, void* stream) {
+  BD_REQUIRE(A && W && out, "bd_gemm_bf16_batched: null operand");
+  BD_REQUIRE(batch > 0 && batch <= 65535, "bd_gemm_bf16_batched: batch=%d", batch);
+  BD_REQUIRE(M > 0 && N > 0 && K > 0 && N % BN == 0 && K % BK == 0,
+             "bd_gemm_bf16_batched: N=%d must be a multiple of %d and K=%d of %d", N, BN, K, BK);
+  BD_REQUIRE(sA >= 0 && sW >= 0 && sOut >= (long long)M * N && sA % 8 == 0 && sW % 8 == 0 && sOut % 8 == 0,
+             "bd_gemm_bf16_batched: bad strides");
+  GemmArgs a{};
+  a.A = (const unsigned short*)A; a.W = (const unsigned short*)W; a.bias = nullptr; a.out = out;
+  a.aux_in = aux; a.aux_out = nullptr;
+  a.M = M; a.Npad = N; a.K = K; a.n_real = N; a.ldc = N;
+  a.sA = sA; a.sW = sW; a.sOut = sOut; a.alpha = alpha; a.beta = beta;
+  a.tiles_n = N / BN;
+  const long long nt = (((long long)M + BM - 1) / BM) * a.tiles_n;
+  BD_REQUIRE(nt < (1ll << 31), "bd_gemm_bf16_batched: too many tiles");
+  a.n_tiles = (int)nt;
+  bd_drop_make(nullptr, 0u, &a.drop);
+  hipStream_t s = (hipStream_t)stream;
+  void* tok = bd_prof_on() ? bd_prof_begin(s) : nullptr;
+  if (aux) hipLaunchKernelGGL((gemm_bf16_kernel<EPI_AXPBY_BF16, false>), dim3(a.n_tiles, batch), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((gemm_bf16_kernel<EPI_BIAS_BF16, false>), dim3(a.n_tiles, batch), dim3(256), 0, s, a);
+  if (tok) bd_prof_end(tok, s, 2.0 * batch * (double)M * N * K);
+  return bd_check_launch("bd_gemm_bf16_batched");
 }
 
 extern "C" int bd_gemm_bf16_aux(const void* A, const void* W, const float* bias, void* out,

@@ -793,6 +793,82 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// =====================================================================================
+// Muon: momentum, then the update matrix is pushed towards the nearest semi-orthogonal matrix by
+// a quintic Newton-Schulz iteration in bf16 (X <- a X + (b A + c A A) X, A = X X^T), on all nb
+// matrices [rows, cols] of a class at once (they sit back to back in the flat buffers).
+// X is kept wide: [r, c] = [min, max] of (rows, cols), i.e. transposed when rows > cols.
+// =====================================================================================
+// buf <- lerp(buf, g, 1 - momentum); u = nesterov ? lerp(g, buf, momentum) : buf (torch's lerp
+// formulas); X <- bf16(u) (wide layout); sumsq[b] += bf16(u)^2. g = grad * clip coefficient.
+__global__ __launch_bounds__(256) void muon_momentum_kernel(const float* __restrict__ grad, float* __restrict__ buf,
+                                                            unsigned short* __restrict__ X, float* __restrict__ sumsq,
+                                                            const float* __restrict__ gsumsq, float max_norm,
+                                                            float w_buf, float momentum, int nesterov, int rows,
+                                                            int cols) {
+  __shared__ float part[4];
+  float coef = 1.f;
+  if (gsumsq != nullptr && max_norm > 0.f) coef = fminf(1.f, max_norm / (sqrtf(gsumsq[0]) + 1e-6f));
+  const int b = blockIdx.y;
+  const long long n = (long long)rows * cols;
+  const bool tr = rows > cols;
+  float ss = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float g = grad[b * n + i] * coef;
+    float m = buf[b * n + i];
+    m = m + w_buf * (g - m);
+    buf[b * n + i] = m;
+    float u = m;
+    if (nesterov) u = momentum < 0.5f ? g + momentum * (m - g) : m - (m - g) * (1.0f - momentum);
+    const unsigned short xb = bd_f32_to_bf16(u);
+    const float xf = bd_bf16_to_f32(xb);
+    ss += xf * xf;
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    X[b * n + (tr ? (long long)c * rows + r : i)] = xb;
+  }
+  ss = bd_wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(sumsq + b, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+// X <- bf16(X / bf16(bf16(norm) + bf16(1e-7)))   (the bf16 tensor arithmetic of x / (x.norm() + eps))
+__global__ __launch_bounds__(256) void muon_normalize_kernel(unsigned short* __restrict__ X, const float* __restrict__ sumsq,
+                                                             long long n) {
+  const int b = blockIdx.y;
+  const float nrm = bd_bf16_to_f32(bd_f32_to_bf16(sqrtf(sumsq[b])));
+  const float den = bd_bf16_to_f32(bd_f32_to_bf16(nrm + bd_bf16_to_f32(bd_f32_to_bf16(1e-7f))));
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    X[b * n + i] = bd_f32_to_bf16(bd_bf16_to_f32(X[b * n + i]) / den);
+}
+
+// out[b][c][r] = in[b][r][c], 64 x 64 tiles through LDS (R, C multiples of 64)
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const unsigned short* __restrict__ in,
+                                                             unsigned short* __restrict__ out, int R, int C) {
+  __shared__ unsigned short tile[64][66];
+  const long long base = (long long)blockIdx.z * R * C;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) tile[i][tx] = in[base + (long long)(r0 + i) * C + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) out[base + (long long)(c0 + i) * R + r0 + tx] = tile[tx][i];
+}
+
+// p <- p (1 - lr wd) - lr scale X   (X back in the parameter's own orientation)
+__global__ __launch_bounds__(256) void muon_apply_kernel(float* __restrict__ param, const unsigned short* __restrict__ X,
+                                                         float decay, float neg_step, int rows, int cols) {
+  const int b = blockIdx.y;
+  const long long n = (long long)rows * cols;
+  const bool tr = rows > cols;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    const float u = bd_bf16_to_f32(X[b * n + (tr ? (long long)c * rows + r : i)]);
+    float pv = param[b * n + i];
+    if (decay != 1.0f) pv = pv * decay;
+    param[b * n + i] = pv + neg_step * u;
+  }
+}
+
 // x bf16 <- fp32 (flat), used to refresh the bf16 weight copies after an optimizer step
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y,
                                                         long long n) {
@@ -1009,4 +1085,54 @@ extern "C" int bd_cast_f32_to_bf16(const float* x, void* y, long long n, void* s
   hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
                      (unsigned short*)y, n);
   return bd_check_launch("bd_cast_f32_to_bf16");
+}
+
+// ------------------------------------------------------------------------------------- Muon
+static long long muon_align(long long x) { return (x + 255) / 256 * 256; }
+
+extern "C" long long bd_muon_workspace_bytes(int nb, int rows, int cols) {
+  const long long r = rows < cols ? rows : cols, c = rows < cols ? cols : rows;
+  return 2 * muon_align(2ll * nb * r * c) + 2 * muon_align(2ll * nb * r * r) + muon_align(4ll * nb);
+}
+
+extern "C" int bd_muon_step(float* params, const float* grads, float* momentum_buf, void* workspace,
+                            long long workspace_bytes, int nb, int rows, int cols, float lr, float weight_decay,
+                            float momentum, int nesterov, int ns_steps, const float* grad_sumsq, float max_norm,
+                            void* stream) {
+  BD_REQUIRE(params && grads && momentum_buf && workspace, "bd_muon_step: null operand");
+  BD_REQUIRE(nb > 0 && nb <= 65535 && rows > 0 && cols > 0 && rows % 128 == 0 && cols % 128 == 0,
+             "bd_muon_step: %d matrices of %d x %d (sizes must be multiples of 128)", nb, rows, cols);
+  BD_REQUIRE(workspace_bytes >= bd_muon_workspace_bytes(nb, rows, cols), "bd_muon_step: workspace too small");
+  BD_REQUIRE(momentum >= 0.f && momentum <= 1.f, "bd_muon_step: momentum=%g", (double)momentum);
+  hipStream_t s = (hipStream_t)stream;
+  const int r = rows < cols ? rows : cols, c = rows < cols ? cols : rows;
+  const long long n = (long long)rows * cols;
+  unsigned char* w = (unsigned char*)workspace;
+  unsigned short* X = (unsigned short*)w;  w += muon_align(2ll * nb * n);
+  unsigned short* Z = (unsigned short*)w;  w += muon_align(2ll * nb * n);
+  unsigned short* A = (unsigned short*)w;  w += muon_align(2ll * nb * r * r);
+  unsigned short* P = (unsigned short*)w;  w += muon_align(2ll * nb * r * r);
+  float* sumsq = (float*)w;
+  if (hipMemsetAsync(sumsq, 0, 4ll * nb, s) != hipSuccess) return bd_fail(BD_ERR_LAUNCH, "bd_muon_step: memset failed");
+  const unsigned gx = (unsigned)((n + 1023) / 1024 < 1024 ? (n + 1023) / 1024 : 1024);
+  hipLaunchKernelGGL(muon_momentum_kernel, dim3(gx, nb), dim3(256), 0, s, grads, momentum_buf, X, sumsq, grad_sumsq, max_norm,
+                     (float)(1.0 - (double)momentum), momentum, nesterov, rows, cols);
+  hipLaunchKernelGGL(muon_normalize_kernel, dim3(gx, nb), dim3(256), 0, s, X, sumsq, n);
+  const int steps = ns_steps < 1 ? 1 : ns_steps;
+  for (int it = 0; it < steps; ++it) {
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3(c / 64, r / 64, nb), dim3(256), 0, s, X, Z, r, c);
+    // A = X X^T;  P = b A + c A A;  X = a X + P X  (P X = P Z^T with Z = X^T)
+    int rc = bd_gemm_bf16_batched(X, X, A, nullptr, nb, n, n, (long long)r * r, r, r, c, 1.f, 0.f, stream);
+    if (rc) return rc;
+    rc = bd_gemm_bf16_batched(A, A, P, A, nb, (long long)r * r, (long long)r * r, (long long)r * r, r, r, r, 2.0315f, -4.7750f,
+                              stream);
+    if (rc) return rc;
+    rc = bd_gemm_bf16_batched(P, Z, X, X, nb, (long long)r * r, n, n, r, c, r, 1.f, 3.4445f, stream);
+    if (rc) return rc;
+  }
+  const float scale = rows > cols ? (float)rows / (float)cols : 1.0f;   // max(1, rows / cols)
+  const float decay = weight_decay != 0.f ? (float)(1.0 - (double)lr * (double)weight_decay) : 1.0f;
+  hipLaunchKernelGGL(muon_apply_kernel, dim3(gx, nb), dim3(256), 0, s, params, X, decay, (float)(-(double)lr * (double)scale),
+                     rows, cols);
+  return bd_check_launch("bd_muon_step");
 }

@@ -316,6 +316,26 @@ int bd_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_
                   float lr, float beta1, float beta2, float eps, float weight_decay, float bias_correction1,
                   float bias_correction2_sqrt, const float* grad_sumsq, float max_norm, void* stream);
 
+/* Batched C_b = A_b W_b^T over `batch` problems of one shape (element strides sA, sW, sOut; bf16 in and
+ * out, row stride N, N % 128 == 0, K % 64 == 0). aux == null: out = acc rounded. aux given (bf16, laid
+ * out like out): out = rn(rn(beta * aux) + rn(alpha * rn(acc))), every step rounded to bf16 as the chain
+ * of bf16 tensor ops in shared/optimizer_setup.py:60-63 is. */
+int bd_gemm_bf16_batched(const void* A, const void* W, void* out, const void* aux, int batch, long long sA,
+                         long long sW, long long sOut, int M, int N, int K, float alpha, float beta,
+                         void* stream);
+
+/* One Muon update of `nb` matrices [rows, cols] stored back to back in params / grads / momentum_buf
+ * (fp32): momentum (lerp, optional Nesterov), normalisation, `ns_steps` quintic Newton-Schulz iterations
+ * in bf16 on the matrix cores, p <- p (1 - lr wd) - lr max(1, rows / cols) X. grad_sumsq / max_norm as
+ * in bd_adamw_step (global-norm clip folded in). rows, cols multiples of 128.
+ * replaces the "muon" group of MuonAdamW.step and _zeropower_via_newtonschulz5,
+ * shared/optimizer_setup.py:43-67,137-167. */
+long long bd_muon_workspace_bytes(int nb, int rows, int cols);
+int bd_muon_step(float* params, const float* grads, float* momentum_buf, void* workspace,
+                 long long workspace_bytes, int nb, int rows, int cols, float lr, float weight_decay,
+                 float momentum, int nesterov, int ns_steps, const float* grad_sumsq, float max_norm,
+                 void* stream);
+
 /* y (bf16) = x (fp32), flat. */
 int bd_cast_f32_to_bf16(const float* x, void* y, long long n, void* stream);
 

@@ -172,3 +172,25 @@ def backbone_inputs(cfg, seed, B=5, L=24):
     ids[0, 3:9] = 1
     t = rs.randint(1, cfg["num_diffusion_steps"] + 1, size=(B,)).astype(np.int64)
     return ids, attn, t
+
+
+# ---- optimizer cases (Muon + AdamW)
+NS_SHAPES = [(128, 128), (128, 256), (256, 128)]
+OPT_STEPS = 3
+OPT_WATCH = ["layers.0.attn.q_proj.weight", "layers.1.attn.out_proj.weight", "layers.0.ffn.fc1.weight",
+             "layers.1.ffn.fc2.weight", "layers.0.ffn.fc1.bias", "layers.1.norm2.weight", "token_embedding.weight",
+             "output_proj.weight"]
+MUON_OPT_CFG = {"optimizer": {"type": "muon_adamw", "muon_adamw": {"enabled": True, "muon_lr_multiplier": 20.0,
+                                                                   "adamw_betas": [0.9, 0.95], "backend_steps": 5}}}
+
+
+def ns_input(shape):
+    rs = np.random.RandomState(1000 + shape[0] + 7 * shape[1])
+    return (rs.standard_normal(shape) * 0.02).astype(np.float32)
+
+
+def optimizer_grads(model, step):
+    """Synthetic gradients per parameter name (frozen stream per step); scaled so that the global norm
+    exceeds 1 and the clip is active."""
+    rs = np.random.RandomState(500 + step)
+    return {n: (rs.standard_normal(tuple(p.shape)) * 0.01).astype(np.float32) for n, p in model.named_parameters()}
