@@ -17,6 +17,7 @@ __device__ __forceinline__ float row_weight(const unsigned char* ind, const long
   return attn ? (float)attn[m] : 1.f;
 }
 
+constexpr int CE_ROWS = 32;   // rows per workgroup: one pair of same-address atomics per 32 rows
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits,
                                                      const long long* __restrict__ targets,
                                                      const unsigned char* __restrict__ ind,
@@ -25,23 +26,34 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
                                                      int M, int V) {
   __shared__ float part[8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + wave;
   float lsum = 0.f, wsum = 0.f;
-  if (row < M) {
+  for (int i = wave; i < CE_ROWS; i += 4) {
+    const int row = blockIdx.x * CE_ROWS + i;
+    if (row >= M) break;
     const float w = row_weight(ind, attn, row);
     float lse = 0.f;
     if (w != 0.f) {
       const float* x = logits + (size_t)row * V;
-      float mx = -INFINITY;
-      for (int v = lane; v < V; v += 64) mx = fmaxf(mx, x[v]);
-      mx = bd_wave_max(mx);
-      float se = 0.f;
-      for (int v = lane; v < V; v += 64) se += __expf(x[v] - mx);
+      float mx = -INFINITY, se = 0.f;
+      if (V <= 1024) {          // the row in registers: one pass over memory
+        float r[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) r[k] = (lane + 64 * k) < V ? x[lane + 64 * k] : -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) mx = fmaxf(mx, r[k]);
+        mx = bd_wave_max(mx);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) se += __expf(r[k] - mx);     // exp(-inf) = 0 past the row
+      } else {
+        for (int v = lane; v < V; v += 64) mx = fmaxf(mx, x[v]);
+        mx = bd_wave_max(mx);
+        for (int v = lane; v < V; v += 64) se += __expf(x[v] - mx);
+      }
       se = bd_wave_sum(se);
       lse = mx + __logf(se);
       const float ce = lse - x[targets[row]];
-      lsum = ce * w;
-      wsum = w;
+      lsum += ce * w;
+      wsum += w;
     }
     if (lane == 0) lse_out[row] = lse;
   }
@@ -743,6 +755,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
   const bool tok_ok = id != pad_id;
   for (int i = lane; i < d; i += 64) {
     const float v = g[i];
+    if (v == 0.f) continue;     // padded rows carry exactly zero gradient: adding it is the identity
     if (tok_ok) atomicAdd(a + i, v);
     atomicAdd(p + i, v);
     atomicAdd(c + i, v);
@@ -885,7 +898,7 @@ extern "C" int bd_masked_ce_fwd(const float* logits, const long long* targets, c
   BD_REQUIRE(logits && targets && indicator && lse && sums, "bd_masked_ce_fwd: null operand");
   BD_REQUIRE(M >= 0 && V > 0, "bd_masked_ce_fwd: bad shape");
   if (M == 0) return BD_OK;
-  hipLaunchKernelGGL(ce_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, targets,
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3((M + CE_ROWS - 1) / CE_ROWS), dim3(256), 0, (hipStream_t)stream, logits, targets,
                      indicator, attention_mask, lse, sums, M, V);
   return bd_check_launch("bd_masked_ce_fwd");
 }
@@ -1057,7 +1070,7 @@ extern "C" int bd_sumsq_f32(const float* x, long long n, float* out, void* strea
   BD_REQUIRE(x && out && n >= 0, "bd_sumsq_f32: bad argument");
   if (n == 0) return BD_OK;
   long long blocks = (n + 4095) / 4096;
-  blocks = blocks > 2048 ? 2048 : blocks;
+  blocks = blocks > 512 ? 512 : blocks;     // one same-address atomic per workgroup: keep them few
   hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, out);
   return bd_check_launch("bd_sumsq_f32");
 }
