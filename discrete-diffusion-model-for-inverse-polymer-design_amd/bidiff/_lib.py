@@ -100,6 +100,7 @@ SIGNATURES = {
     "bd_device_available": (C.c_int, []),
     "bd_dropout_f32": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, C.c_uint, VP]),
     "bd_dropout_f32_to_bf16": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, C.c_uint, VP]),
+    "bd_collate_batch": (C.c_int, [VP, VP, VP, C.c_longlong, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP]),
     "bd_pool_hidden": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "bd_embed_drop": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP, C.c_uint, VP]),
     "bd_gemm_bf16_drop": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -1,0 +1,59 @@
+"""Training batches assembled on the device: stands where the reference has
+``DataLoader(PolymerDataset, batch_sampler=LengthBucketBatchSampler, collate_fn=dynamic_collate_fn)``
+(src/data/dataset.py:200-240, scripts/step1_train_backbone.py) and yields the same dicts
+(``input_ids`` / ``attention_mask`` int64 [B, L]), already on the GPU. Per batch the host sends the
+B row indices (pinned, asynchronous); ``bd_collate_batch`` gathers and pads from the resident store.
+``pad_to_max_length=True`` gives the fixed-length batches of the default ``collate_fn``;
+False pads to the longest row of the batch (``dynamic_collate_fn``)."""
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+class DeviceBatchLoader:
+    def __init__(self, store, batch_sampler, device, pad_to_max_length: bool = False):
+        self.store, self.batch_sampler = store, batch_sampler
+        self.device = torch.device(device)
+        self.pad_to_max_length = bool(pad_to_max_length)
+        self._tok, self._off = store.to_device(self.device)
+        self._err = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._pinned = None
+
+    def __len__(self):
+        return len(self.batch_sampler)
+
+    def set_epoch(self, epoch: int):
+        if hasattr(self.batch_sampler, "set_epoch"):
+            self.batch_sampler.set_epoch(epoch)
+
+    def assemble(self, indices):
+        """One batch from store rows ``indices`` (any sequence of ints)."""
+        idx = np.asarray(indices, dtype=np.int64)
+        B = int(idx.size)
+        if B == 0:
+            raise ValueError("DeviceBatchLoader: empty batch")
+        if idx.min() < 0 or idx.max() >= len(self.store):
+            raise IndexError("DeviceBatchLoader: sample index out of range")
+        L = self.store.max_length if self.pad_to_max_length else int(self.store.lengths[idx].max())
+        if self._pinned is None or self._pinned.numel() < B:
+            self._pinned = torch.empty(max(B, 1024), dtype=torch.long).pin_memory()
+        self._pinned[:B].copy_(torch.from_numpy(idx))
+        didx = self._pinned[:B].to(self.device, non_blocking=True)
+        ids = torch.empty(B, L, dtype=torch.long, device=self.device)
+        mask = torch.empty(B, L, dtype=torch.long, device=self.device)
+        rc = _lib.lib().bd_collate_batch(_lib.ptr(self._tok), _lib.ptr(self._off), _lib.ptr(didx), len(self.store), B, L,
+                                         self.store.pad_token_id, _lib.ptr(ids), _lib.ptr(mask), _lib.ptr(self._err),
+                                         _lib.stream_handle())
+        _lib.check(rc, "bd_collate_batch")
+        return {"input_ids": ids, "attention_mask": mask}
+
+    def __iter__(self):
+        for batch in self.batch_sampler:
+            yield self.assemble(batch)
+
+    def check(self):
+        """Raises if any batch so far hit an out-of-range row or an over-long sequence (one host sync)."""
+        flag = int(self._err.item())
+        if flag:
+            raise RuntimeError(f"bd_collate_batch reported error bits {flag:#x} (1: index out of range, 2: row longer than L)")

@@ -97,6 +97,39 @@ __global__ __launch_bounds__(256) void pool_kernel(const unsigned short* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------
+// Batch assembly from a token store resident in HBM: sequence i of the batch is store row
+// indices[i], tokens[offsets[row] .. offsets[row + 1]) (uint16, BOS/EOS already in place);
+// ids_out[i, :] = those tokens then pad, attention_mask 1 on the tokens, int64 as the model's
+// interface takes them. One wave per sequence.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void collate_kernel(const unsigned short* __restrict__ tokens,
+                                                      const long long* __restrict__ offsets,
+                                                      const long long* __restrict__ indices, long long n_rows,
+                                                      int B, int L, int pad_id, long long* __restrict__ ids_out,
+                                                      long long* __restrict__ mask_out, int* __restrict__ err) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= B) return;
+  const long long row = indices[i];
+  long long start = 0, len = 0;
+  if (row < 0 || row >= n_rows) {
+    if (lane == 0) atomicOr(err, 1);
+  } else {
+    start = offsets[row];
+    len = offsets[row + 1] - start;
+    if (len > L) {
+      if (lane == 0) atomicOr(err, 2);
+      len = L;
+    }
+  }
+  for (int l = lane; l < L; l += 64) {
+    const bool in = l < len;
+    ids_out[(size_t)i * L + l] = in ? (long long)tokens[start + l] : (long long)pad_id;
+    mask_out[(size_t)i * L + l] = in ? 1 : 0;
+  }
+}
+
 // out[m, n] = x[m, n] * keep / (1 - p), fp32 or bf16 result; one thread per four columns
 template <bool BF16_OUT>
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, void* __restrict__ out,
@@ -228,6 +261,16 @@ extern "C" int bd_pool_hidden(const void* hidden_bf16, const long long* attentio
   hipLaunchKernelGGL(pool_kernel, dim3(B, (d + 511) / 512), dim3(256), 0, (hipStream_t)stream,
                      (const unsigned short*)hidden_bf16, mode == 1 ? nullptr : attention_mask, out, L, d, mode);
   return bd_check_launch("bd_pool_hidden");
+}
+
+extern "C" int bd_collate_batch(const void* tokens_u16, const long long* offsets, const long long* indices,
+                                long long n_rows, int B, int L, int pad_id, long long* ids_out,
+                                long long* attention_mask_out, int* error_flag, void* stream) {
+  BD_REQUIRE(tokens_u16 && offsets && indices && ids_out && attention_mask_out && error_flag, "bd_collate_batch: null operand");
+  BD_REQUIRE(B > 0 && L > 0 && n_rows > 0, "bd_collate_batch: bad shape B=%d L=%d rows=%lld", B, L, n_rows);
+  hipLaunchKernelGGL(collate_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)tokens_u16,
+                     offsets, indices, n_rows, B, L, pad_id, ids_out, attention_mask_out, error_flag);
+  return bd_check_launch("bd_collate_batch");
 }
 
 static int dropout_launch(const float* x, void* out, int M, int N, const bd_dropout* drop, unsigned site, bool bf16,

@@ -215,6 +215,19 @@ int bd_corrupt(const long long* ids, const long long* attention_mask, const long
                int pad_id, int bos_id, int eos_id, unsigned long long seed, long long seq_offset,
                void* stream);
 
+/* ---------------------------------------------------------------- training input */
+
+/* Batch assembly from a pre-tokenised store resident in device memory: tokens (uint16, all sequences
+ * back to back with BOS / EOS in place), offsets [n_rows + 1] (int64), indices [B] (int64 store rows of
+ * this batch). Writes ids_out [B, L] = tokens then pad_id and attention_mask_out [B, L] = 1 on tokens
+ * (int64). error_flag (device int, caller zeroes) gets bit 0 for an index out of range and bit 1 for a
+ * sequence longer than L (it is cut to L).
+ * replaces PolymerDataset.__getitem__ + collate_fn / dynamic_collate_fn, src/data/dataset.py:66-84,200-240
+ * (tokenisation itself happens once, on the host, when the store is built). */
+int bd_collate_batch(const void* tokens_u16, const long long* offsets, const long long* indices,
+                     long long n_rows, int B, int L, int pad_id, long long* ids_out,
+                     long long* attention_mask_out, int* error_flag, void* stream);
+
 /* ---------------------------------------------------------------- training step */
 
 /* Training dropout (nn.Dropout / SDPA dropout_p, src/model/backbone.py:30,65,93,98,100,185,247).

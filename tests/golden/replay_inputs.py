@@ -194,3 +194,27 @@ def optimizer_grads(model, step):
     exceeds 1 and the clip is active."""
     rs = np.random.RandomState(500 + step)
     return {n: (rs.standard_normal(tuple(p.shape)) * 0.01).astype(np.float32) for n, p in model.named_parameters()}
+
+
+# ---- training input pipeline cases
+SAMPLER_CASES = [  # (n, batch_size, drop_last, shuffle, seed, bucket_multiplier, replicas, rank, epoch)
+    (1000, 32, False, True, 42, 50, 1, 0, 0), (1000, 32, True, True, 42, 3, 1, 0, 2), (1003, 16, False, True, 7, 4, 4, 1, 1),
+    (1003, 16, True, True, 7, 4, 4, 3, 0), (257, 64, False, False, 1, 2, 2, 0, 5), (10, 4, False, True, 3, 50, 3, 2, 0)]
+POLYMER_MAX_LENGTH = 40
+
+
+def sampler_lengths(n):
+    return np.clip(np.round(np.random.RandomState(n).normal(38.5, 15.0, size=n)), 12, 128).astype(np.int64)
+
+
+def polymer_strings(n=120, seed=4):
+    """Synthetic p-SMILES-like strings over the reference tokenizer's alphabet (two-letter atoms, brackets,
+    ring digits, %nn, bonds, stars); some exceed POLYMER_MAX_LENGTH tokens and get truncated."""
+    rs = np.random.RandomState(seed)
+    parts = ["C", "c", "N", "O", "S", "F", "Cl", "Br", "Si", "(", ")", "=", "#", "1", "2", "3", "%10", "%11", "[NH]", "[Si]",
+             "[O-]", "/", "\\", "-", "n", "o", "s", "P", "I"]
+    out = []
+    for _ in range(n):
+        k = int(rs.randint(3, 60))
+        out.append("*" + "".join(parts[int(i)] for i in rs.randint(0, len(parts), size=k)) + "*")
+    return out
