@@ -62,6 +62,11 @@ class Dropout(C.Structure):
     _fields_ = [("p", C.c_float), ("step", C.c_uint), ("seed", C.c_ulonglong)]
 
 
+class CastJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("ld", C.c_int),
+                ("transpose", C.c_int)]
+
+
 class StepArgs(C.Structure):
     _fields_ = [
         ("ids", VP), ("fixed", VP), ("attn", VP), ("keymask", VP), ("has_eos", VP),
@@ -127,6 +132,7 @@ SIGNATURES = {
     "bd_embed_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "bd_sumsq_f32": (C.c_int, [VP, C.c_longlong, VP, VP]),
     "bd_adamw_step": (C.c_int, [VP, VP, VP, VP, C.c_longlong] + [C.c_float] * 7 + [VP, C.c_float, VP]),
+    "bd_multi_cast_bf16": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP]),
     "bd_cast_f32_to_bf16": (C.c_int, [VP, VP, C.c_longlong, VP]),
     "bd_gemm_panel_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "bd_gemm_panel": (C.c_int, [VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, VP]),

@@ -72,11 +72,13 @@ def _to_bf16(x, out, drop=None, site=0):
 class _TrainWeights:
     """bf16 copies (and transposes for the data-gradient GEMMs) of the current parameters. Head sizes
     the attention kernels do not have (e.g. 48) are zero-padded to 32 / 64 / 128 (``dhp``); the q rows
-    absorb sqrt(dhp / dh) because the kernels scale by 1 / sqrt(dhp)."""
+    absorb sqrt(dhp / dh) because the kernels scale by 1 / sqrt(dhp).
+
+    Without head padding the copies live in persistent buffers that ONE launch (bd_multi_cast_bf16
+    over a job table of all matrices) refreshes after each optimizer step."""
 
     def __init__(self, model):
         d, V, H = model.hidden_size, model.vocab_size, model.num_heads
-        bf = torch.bfloat16
         dh = d // H
         if dh > 128:
             raise NotImplementedError("bidiff attention kernels support head_dim <= 128")
@@ -85,11 +87,69 @@ class _TrainWeights:
         self.aw = aw = H * dhp
         if aw % 128:
             raise NotImplementedError(f"bidiff: num_heads * padded head_dim = {aw} must be a multiple of 128")
-        self.qfix = qfix = (dhp / dh) ** 0.5
+        self.qfix = (dhp / dh) ** 0.5
+        self.vpad = (V + 127) // 128 * 128
+        self.ptr_key = tuple(p.data_ptr() for p in model.parameters())
+        self.jobs = None
+        if dhp == dh:
+            self._build_persistent(model)
+        else:
+            self._build_padded(model)
+
+    def _build_persistent(self, model):
+        d, F, V = model.hidden_size, model.ffn_hidden_size, model.vocab_size
+        dev = model.output_proj.weight.device
+        bf = torch.bfloat16
+        jobs = []
+
+        def job(src, dst, ld, mode, row_off=0, col_off=0):
+            rows, cols = (src.shape if src.dim() == 2 else (1, src.shape[0]))
+            esz = 4 if mode == 2 else 2
+            jobs.append(_lib.CastJob(src.data_ptr(), dst.data_ptr() + esz * (row_off * ld + col_off), rows, cols, ld, mode))
+
+        self.layers = []
+        for blk in model.layers:
+            a = blk.attn
+            w = {"wqkv": torch.empty(3 * d, d, dtype=bf, device=dev), "wqkvT": torch.empty(d, 3 * d, dtype=bf, device=dev),
+                 "bqkv": torch.empty(3 * d, device=dev),
+                 "wo": torch.empty(d, d, dtype=bf, device=dev), "woT": torch.empty(d, d, dtype=bf, device=dev),
+                 "w1": torch.empty(F, d, dtype=bf, device=dev), "w1T": torch.empty(d, F, dtype=bf, device=dev),
+                 "w2": torch.empty(d, F, dtype=bf, device=dev), "w2T": torch.empty(F, d, dtype=bf, device=dev)}
+            for i, pr in enumerate((a.q_proj, a.k_proj, a.v_proj)):
+                job(pr.weight, w["wqkv"], d, 0, row_off=i * d)
+                job(pr.weight, w["wqkvT"], 3 * d, 1, col_off=i * d)
+                job(pr.bias, w["bqkv"], 3 * d, 2, col_off=i * d)
+            job(a.out_proj.weight, w["wo"], d, 0)
+            job(a.out_proj.weight, w["woT"], d, 1)
+            job(blk.ffn.fc1.weight, w["w1"], d, 0)
+            job(blk.ffn.fc1.weight, w["w1T"], F, 1)
+            job(blk.ffn.fc2.weight, w["w2"], F, 0)
+            job(blk.ffn.fc2.weight, w["w2T"], d, 1)
+            self.layers.append(w)
+        self.wout = torch.zeros(self.vpad, d, dtype=bf, device=dev)          # rows past V stay zero
+        self.woutT = torch.zeros(d, self.vpad, dtype=bf, device=dev)
+        job(model.output_proj.weight, self.wout, d, 0)
+        job(model.output_proj.weight, self.woutT, self.vpad, 1)
+        arr = (_lib.CastJob * len(jobs))(*jobs)
+        self.jobs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        self.n_jobs = len(jobs)
+        self.max_rows = max(j.rows for j in jobs)
+        self.max_cols = max(j.cols for j in jobs)
+        self.refresh(model)
+
+    def refresh(self, model):
+        if self.jobs is None:
+            self._build_padded(model)
+            return
+        _ck(_lib.lib().bd_multi_cast_bf16(_lib.ptr(self.jobs), self.n_jobs, self.max_rows, self.max_cols, _s()),
+            "bd_multi_cast_bf16")
+
+    def _build_padded(self, model):
+        d, V, H = model.hidden_size, model.vocab_size, model.num_heads
+        bf = torch.bfloat16
+        dh, dhp, aw, qfix = self.dh, self.dhp, self.aw, self.qfix
 
         def pad_rows(w):       # [H*dh, ...] -> [H*dhp, ...]
-            if dhp == dh:
-                return w
             out = w.new_zeros((H, dhp) + tuple(w.shape[1:]))
             out[:, :dh] = w.view((H, dh) + tuple(w.shape[1:]))
             return out.view((aw,) + tuple(w.shape[1:]))
@@ -100,7 +160,7 @@ class _TrainWeights:
                 a = blk.attn
                 wqkv = torch.cat([pad_rows(a.q_proj.weight * qfix), pad_rows(a.k_proj.weight), pad_rows(a.v_proj.weight)], 0)
                 bqkv = torch.cat([pad_rows(a.q_proj.bias * qfix), pad_rows(a.k_proj.bias), pad_rows(a.v_proj.bias)], 0)
-                wo = a.out_proj.weight if dhp == dh else pad_rows(a.out_proj.weight.t().contiguous()).t()
+                wo = pad_rows(a.out_proj.weight.t().contiguous()).t()
                 self.layers.append({
                     "wqkv": wqkv.to(bf).contiguous(), "wqkvT": wqkv.t().to(bf).contiguous(),
                     "bqkv": bqkv.float().contiguous(),
@@ -108,7 +168,6 @@ class _TrainWeights:
                     "w1": blk.ffn.fc1.weight.to(bf).contiguous(), "w1T": blk.ffn.fc1.weight.t().to(bf).contiguous(),
                     "w2": blk.ffn.fc2.weight.to(bf).contiguous(), "w2T": blk.ffn.fc2.weight.t().to(bf).contiguous(),
                 })
-            self.vpad = (V + 127) // 128 * 128
             wout = torch.zeros(self.vpad, d, dtype=bf, device=model.output_proj.weight.device)
             wout[:V] = model.output_proj.weight.to(bf)
             self.wout = wout
@@ -118,9 +177,14 @@ class _TrainWeights:
 def _train_weights(model):
     key = model._pack_key()
     tw = getattr(model, "_train_w", None)
-    if tw is None or tw[0] != key:
-        tw = (key, _TrainWeights(model))
-        model._train_w = tw
+    if tw is not None and tw[0] == key:
+        return tw[1]
+    if tw is not None and tw[1].ptr_key == tuple(p.data_ptr() for p in model.parameters()):
+        tw[1].refresh(model)          # same storage, new values: one launch
+        model._train_w = (key, tw[1])
+        return tw[1]
+    tw = (key, _TrainWeights(model))
+    model._train_w = tw
     return tw[1]
 
 

@@ -882,6 +882,38 @@ __global__ __launch_bounds__(256) void muon_apply_kernel(float* __restrict__ par
   }
 }
 
+// Many fp32 -> bf16 copies in one launch (the bf16 weight copies and their transposes that the
+// training GEMMs read, refreshed after every optimizer step): job j copies src [rows, cols] to
+// dst[r * ld + c], or transposed to dst[c * ld + r]. 64 x 64 tiles through LDS; gridDim.y = jobs,
+// gridDim.x = tiles of the largest job (workgroups past a job's tile count leave).
+__global__ __launch_bounds__(256) void multi_cast_kernel(const bd_cast_job* __restrict__ jobs) {
+  __shared__ float tile[64][65];
+  const bd_cast_job j = jobs[blockIdx.y];
+  const int tc = (j.cols + 63) / 64, tr = (j.rows + 63) / 64;
+  if ((int)blockIdx.x >= tc * tr) return;
+  const int r0 = (blockIdx.x / tc) * 64, c0 = (blockIdx.x % tc) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  unsigned short* dst = (unsigned short*)j.dst;
+  if (j.transpose & 2) {        // plain fp32 copy (stacked biases)
+    if (c0 + tx < j.cols)
+      for (int i = ty; i < 64 && r0 + i < j.rows; i += 4)
+        ((float*)j.dst)[(size_t)(r0 + i) * j.ld + c0 + tx] = j.src[(size_t)(r0 + i) * j.cols + c0 + tx];
+    return;
+  }
+  if (!j.transpose) {
+    if (c0 + tx < j.cols)
+      for (int i = ty; i < 64 && r0 + i < j.rows; i += 4)
+        dst[(size_t)(r0 + i) * j.ld + c0 + tx] = bd_f32_to_bf16(j.src[(size_t)(r0 + i) * j.cols + c0 + tx]);
+    return;
+  }
+  for (int i = ty; i < 64; i += 4)
+    tile[i][tx] = (r0 + i < j.rows && c0 + tx < j.cols) ? j.src[(size_t)(r0 + i) * j.cols + c0 + tx] : 0.f;
+  __syncthreads();
+  if (r0 + tx < j.rows)
+    for (int i = ty; i < 64 && c0 + i < j.cols; i += 4)
+      dst[(size_t)(c0 + i) * j.ld + r0 + tx] = bd_f32_to_bf16(tile[tx][i]);
+}
+
 // x bf16 <- fp32 (flat), used to refresh the bf16 weight copies after an optimizer step
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y,
                                                         long long n) {
@@ -1148,4 +1180,12 @@ extern "C" int bd_muon_step(float* params, const float* grads, float* momentum_b
   hipLaunchKernelGGL(muon_apply_kernel, dim3(gx, nb), dim3(256), 0, s, params, X, decay, (float)(-(double)lr * (double)scale),
                      rows, cols);
   return bd_check_launch("bd_muon_step");
+}
+
+extern "C" int bd_multi_cast_bf16(const bd_cast_job* jobs_device, int n_jobs, int max_rows, int max_cols, void* stream) {
+  BD_REQUIRE(jobs_device && n_jobs > 0 && n_jobs <= 65535 && max_rows > 0 && max_cols > 0, "bd_multi_cast_bf16: bad argument");
+  const long long tiles = (long long)((max_rows + 63) / 64) * ((max_cols + 63) / 64);
+  BD_REQUIRE(tiles < (1ll << 31), "bd_multi_cast_bf16: job too large");
+  hipLaunchKernelGGL(multi_cast_kernel, dim3((unsigned)tiles, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_device);
+  return bd_check_launch("bd_multi_cast_bf16");
 }

@@ -349,6 +349,18 @@ int bd_muon_step(float* params, const float* grads, float* momentum_buf, void* w
                  float momentum, int nesterov, int ns_steps, const float* grad_sumsq, float max_norm,
                  void* stream);
 
+/* Many fp32 -> bf16 copies in one launch: job j copies src [rows, cols] (contiguous) to dst[r * ld + c],
+ * or, with transpose == 1, to dst[c * ld + r]; transpose == 2 copies fp32 to fp32 dst[r * ld + c] (stacked
+ * biases). jobs_device is a device array; max_rows / max_cols bound
+ * every job's shape. (The bf16 weight copies autocast makes per GEMM in the reference's training step,
+ * trainer_backbone.py:434-436, plus the transposes the data-gradient GEMMs read.) */
+typedef struct bd_cast_job {
+  const float* src;
+  void* dst;
+  int rows, cols, ld, transpose;
+} bd_cast_job;
+int bd_multi_cast_bf16(const bd_cast_job* jobs_device, int n_jobs, int max_rows, int max_cols, void* stream);
+
 /* y (bf16) = x (fp32), flat. */
 int bd_cast_f32_to_bf16(const float* x, void* y, long long n, void* stream);
 

@@ -404,3 +404,64 @@ def test_trainer_runs_and_checkpoints(gpu_device, tmp_path):
     assert list(ck["model_state_dict"].keys()) == list(sd.keys())
     assert (tmp_path / "metrics" / "backbone_loss_curve.csv").exists()
     tr.load_checkpoint(str(tmp_path / "checkpoints" / "backbone_best.pt"))
+
+
+def test_multi_cast_jobs(gpu_device):
+    """One launch, many fp32 -> bf16 copies: plain, transposed, into sub-blocks with a leading dimension,
+    ragged shapes, and the fp32 pass-through used for stacked biases."""
+    dev = gpu_device
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn(384, 384, generator=g).to(dev)
+    b = torch.randn(803, 128, generator=g).to(dev)
+    c = torch.randn(70, 33, generator=g).to(dev)
+    bias = torch.randn(384, generator=g).to(dev)
+    stack = torch.full((3 * 384, 384), 7.0, dtype=torch.bfloat16, device=dev)
+    stackT = torch.full((384, 3 * 384), 7.0, dtype=torch.bfloat16, device=dev)
+    bT = torch.zeros(128, 896, dtype=torch.bfloat16, device=dev)
+    cc = torch.zeros(70, 40, dtype=torch.bfloat16, device=dev)
+    cT = torch.zeros(33, 70, dtype=torch.bfloat16, device=dev)
+    bst = torch.zeros(3 * 384, device=dev)
+    jobs = [_lib.CastJob(a.data_ptr(), stack.data_ptr() + 2 * 384 * 384, 384, 384, 384, 0),          # rows 384..767
+            _lib.CastJob(a.data_ptr(), stackT.data_ptr() + 2 * 384, 384, 384, 3 * 384, 1),          # columns 384..767
+            _lib.CastJob(b.data_ptr(), bT.data_ptr(), 803, 128, 896, 1),
+            _lib.CastJob(c.data_ptr(), cc.data_ptr(), 70, 33, 40, 0),
+            _lib.CastJob(c.data_ptr(), cT.data_ptr(), 70, 33, 70, 1),
+            _lib.CastJob(bias.data_ptr(), bst.data_ptr() + 4 * 768, 1, 384, 3 * 384, 2)]
+    arr = (_lib.CastJob * len(jobs))(*jobs)
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    _lib.check(_lib.lib().bd_multi_cast_bf16(_lib.ptr(table), len(jobs), 803, 384, _s()), "multi_cast")
+    torch.cuda.synchronize()
+    assert torch.equal(stack[384:768], a.bfloat16()) and (stack[:384] == 7).all() and (stack[768:] == 7).all()
+    assert torch.equal(stackT[:, 384:768], a.t().bfloat16()) and (stackT[:, :384] == 7).all() and (stackT[:, 768:] == 7).all()
+    assert torch.equal(bT[:, :803], b.t().bfloat16()) and (bT[:, 803:] == 0).all()
+    assert torch.equal(cc[:, :33], c.bfloat16()) and (cc[:, 33:] == 0).all()
+    assert torch.equal(cT, c.t().bfloat16())
+    assert torch.equal(bst[768:], bias) and (bst[:768] == 0).all()
+
+
+def test_training_weight_copies_follow_the_parameters(gpu_device):
+    """The persistent bf16 copies are refreshed (one launch) after an optimizer step and equal fresh casts."""
+    dev = gpu_device
+    cfg, model, sd, ids, attn, t = _grad_setup("tiny_h2", dev)
+    model.train()
+    bb = model.backbone
+    opt = FlatAdamW(model.parameters(), lr=1e-2)
+    for _ in range(2):
+        out = model(ids.to(dev), attn.to(dev))
+        out["loss"].backward()
+        opt.step()
+        opt.zero_grad()
+    tw = AG._train_weights(bb)
+    assert tw.jobs is not None
+    blk = bb.layers[1]
+    w = tw.layers[1]
+    want = torch.cat([blk.attn.q_proj.weight, blk.attn.k_proj.weight, blk.attn.v_proj.weight], 0)
+    assert torch.equal(w["wqkv"], want.bfloat16()) and torch.equal(w["wqkvT"], want.t().bfloat16())
+    assert torch.equal(w["bqkv"], torch.cat([blk.attn.q_proj.bias, blk.attn.k_proj.bias, blk.attn.v_proj.bias]))
+    assert torch.equal(w["w1T"], blk.ffn.fc1.weight.t().bfloat16()) and torch.equal(w["w2"], blk.ffn.fc2.weight.bfloat16())
+    assert torch.equal(w["woT"], blk.attn.out_proj.weight.t().bfloat16())
+    V = cfg["vocab_size"]
+    assert torch.equal(tw.wout[:V], bb.output_proj.weight.bfloat16()) and (tw.wout[V:] == 0).all()
+    assert torch.equal(tw.woutT[:, :V], bb.output_proj.weight.t().bfloat16()) and (tw.woutT[:, V:] == 0).all()
+    same = AG._train_weights(bb)
+    assert same is tw
