@@ -149,11 +149,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
     if (DROP) {
       const uint32_t prow = (uint32_t)(((size_t)b * H + h) * L + (q0 + c));
 #pragma unroll
-      for (int tile = 0; tile < 8; ++tile) {
-        const int key0 = kt0 + 32 * (tile >> 1) + 8 * g + 4 * (tile & 1);
-        const bd_philox_out w = bd_drop_words(drop, prow, (uint32_t)(key0 >> 2));
+      for (int s4 = 0; s4 < 4; ++s4) {      // tiles 2 s4, 2 s4 + 1 = keys key0 .. key0 + 7: one block
+        const int key0 = kt0 + 32 * s4 + 8 * g;
+        const bd_philox_out w = bd_drop_block(drop, prow, (uint32_t)(key0 >> 3));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[tile][r] *= bd_drop_factor(drop, w.v[r]);
+        for (int r = 0; r < 4; ++r) {
+          s[2 * s4][r] *= bd_drop_factor(drop, w, r);
+          s[2 * s4 + 1][r] *= bd_drop_factor(drop, w, 4 + r);
+        }
       }
     }
 

@@ -8,7 +8,8 @@ static inline bool bd_drop_make(const bd_dropout* d, unsigned site, bd_drop_args
   out->thr = 0u; out->k0 = 0u; out->k1 = 0u; out->site = site; out->step = 0u; out->scale = 1.0f;
   if (d == nullptr || d->p == 0.0f) return true;
   if (!(d->p > 0.0f && d->p < 1.0f)) return false;
-  out->thr = (uint32_t)((double)d->p * 4294967296.0);
+  out->thr = (uint32_t)((double)d->p * 65536.0);
+  if (out->thr == 0u) return true;      // p below the 16-bit resolution: off
   out->scale = 1.0f / (1.0f - d->p);
   out->k0 = (uint32_t)d->seed;
   out->k1 = (uint32_t)(d->seed >> 32);

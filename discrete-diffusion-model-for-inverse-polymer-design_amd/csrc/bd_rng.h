@@ -49,15 +49,20 @@ BD_HD float bd_uniform_token(uint64_t seed, uint32_t seq, uint32_t t, uint32_t p
 }
 
 // ---- training dropout: keep decisions as a pure function of (seed, step, site, row, column).
-// One Philox block, counter (column / 4, row, site, step), holds the 32-bit words of four
-// neighbouring columns; an element is kept iff its word >= thr = floor(p * 2^32) and is then
-// scaled by 1 / (1 - p). thr == 0 keeps everything (scale 1): dropout off.
+// One Philox block, counter (column / 8, row, site, step), serves eight neighbouring columns:
+// column c takes 16 bits of it, the low (c even) or high (c odd) half of word (c % 8) / 2, and is
+// kept iff that number >= thr = floor(p * 2^16); kept elements are scaled by 1 / (1 - p).
+// thr == 0 keeps everything (scale 1): dropout off.
 struct bd_drop_args { uint32_t thr, k0, k1, site, step; float scale; };
 
-BD_HD bd_philox_out bd_drop_words(const bd_drop_args& d, uint32_t row, uint32_t col4) {
-  return bd_philox4x32_10(col4, row, d.site, d.step, d.k0, d.k1);
+BD_HD bd_philox_out bd_drop_block(const bd_drop_args& d, uint32_t row, uint32_t col8) {
+  return bd_philox4x32_10(col8, row, d.site, d.step, d.k0, d.k1);
 }
-BD_HD float bd_drop_factor(const bd_drop_args& d, uint32_t word) { return word >= d.thr ? d.scale : 0.0f; }
+// factor of column j (0..7) of the block
+BD_HD float bd_drop_factor(const bd_drop_args& d, const bd_philox_out& w, int j) {
+  const uint32_t h = (w.v[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+  return h >= d.thr ? d.scale : 0.0f;
+}
 
 // -ln(x) for finite x > 0, fp32 multiplies/adds only (polynomial after Cephes logf).
 BD_HD float bd_neglog(float x) {

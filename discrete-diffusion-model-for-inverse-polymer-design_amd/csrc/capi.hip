@@ -61,9 +61,9 @@ extern "C" int bd_host_dropout_factors(const bd_dropout* drop, unsigned site, lo
   bd_drop_args da;
   if (!bd_drop_make(drop, site, &da)) return -1;
   for (long long r = 0; r < rows; ++r)
-    for (long long c4 = 0; 4 * c4 < cols; ++c4) {
-      const bd_philox_out w = bd_drop_words(da, (uint32_t)r, (uint32_t)c4);
-      for (int i = 0; i < 4 && 4 * c4 + i < cols; ++i) out[r * cols + 4 * c4 + i] = bd_drop_factor(da, w.v[i]);
+    for (long long c8 = 0; 8 * c8 < cols; ++c8) {
+      const bd_philox_out w = bd_drop_block(da, (uint32_t)r, (uint32_t)c8);
+      for (int i = 0; i < 8 && 8 * c8 + i < cols; ++i) out[r * cols + 8 * c8 + i] = bd_drop_factor(da, w, i);
     }
   return 0;
 }

@@ -31,9 +31,10 @@ __global__ __launch_bounds__(256) void embed_kernel(const long long* __restrict_
     r[0] = (va[0] + vb[0]) + vc[0]; r[1] = (va[1] + vb[1]) + vc[1];
     r[2] = (va[2] + vb[2]) + vc[2]; r[3] = (va[3] + vb[3]) + vc[3];
     if (drop.thr != 0u) {
-      const bd_philox_out w = bd_drop_words(drop, (uint32_t)row, (uint32_t)i);
-      r[0] *= bd_drop_factor(drop, w.v[0]); r[1] *= bd_drop_factor(drop, w.v[1]);
-      r[2] *= bd_drop_factor(drop, w.v[2]); r[3] *= bd_drop_factor(drop, w.v[3]);
+      const bd_philox_out w = bd_drop_block(drop, (uint32_t)row, (uint32_t)(i >> 1));
+      const int j0 = 4 * (i & 1);
+      r[0] *= bd_drop_factor(drop, w, j0);     r[1] *= bd_drop_factor(drop, w, j0 + 1);
+      r[2] *= bd_drop_factor(drop, w, j0 + 2); r[3] *= bd_drop_factor(drop, w, j0 + 3);
     }
     o[i] = r;
   }
@@ -138,9 +139,10 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
     const uint32_t row = (uint32_t)(i / N4), c4 = (uint32_t)(i % N4);
     f32x4 v = ((const f32x4*)x)[i];
-    const bd_philox_out w = bd_drop_words(drop, row, c4);
-    v[0] *= bd_drop_factor(drop, w.v[0]); v[1] *= bd_drop_factor(drop, w.v[1]);
-    v[2] *= bd_drop_factor(drop, w.v[2]); v[3] *= bd_drop_factor(drop, w.v[3]);
+    const bd_philox_out w = bd_drop_block(drop, row, c4 >> 1);
+    const int j0 = 4 * (int)(c4 & 1u);
+    v[0] *= bd_drop_factor(drop, w, j0);     v[1] *= bd_drop_factor(drop, w, j0 + 1);
+    v[2] *= bd_drop_factor(drop, w, j0 + 2); v[3] *= bd_drop_factor(drop, w, j0 + 3);
     if (BF16_OUT) {
       u32x2 o;
       o[0] = bd_pack_bf16x2(v[0], v[1]); o[1] = bd_pack_bf16x2(v[2], v[3]);

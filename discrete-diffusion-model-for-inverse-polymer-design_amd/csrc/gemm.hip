@@ -45,34 +45,34 @@ struct GemmArgs {
 __device__ __forceinline__ int swz_a(int row) { return row & 7; }
 __device__ __forceinline__ int swz_w(int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); }
 
-// erf by Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, far below bf16 resolution)
-__device__ __forceinline__ float erf_as(float x) {
-  const float ax = fabsf(x);
-  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
-  float p = 1.061405429f;
-  p = p * t + -1.453152027f;
-  p = p * t + 1.421413741f;
-  p = p * t + -0.284496736f;
-  p = p * t + 0.254829592f;
-  const float y = 1.0f - p * t * __expf(-ax * ax);
-  return copysignf(y, x);
+// Phi(x) = 0.5 (1 + erf(x / sqrt 2)) as clamp(0.5 + x P(min(x^2, 16)), 0, 1): x P(x^2) is a degree-7
+// odd minimax fit of 0.5 erf(x / sqrt 2) on |x| <= 4, past that the product overshoots +-0.5 and
+// the clamp saturates it. |error| < 2e-4, below the bf16 rounding of the activations; no
+// transcendental (the same polynomial the fused inference kernels evaluate).
+__device__ __forceinline__ float norm_cdf(float x) {
+  const float s = fminf(x * x, 16.0f);
+  float p = s * -1.903182666e-09f + 1.410586241e-07f;
+  p = p * s + -4.565313249e-06f;
+  p = p * s + 8.634553992e-05f;
+  p = p * s + -1.085383136e-03f;
+  p = p * s + 9.789848745e-03f;
+  p = p * s + -6.636063135e-02f;
+  p = p * s + 3.989269649e-01f;
+  return __builtin_amdgcn_fmed3f(x * p + 0.5f, 0.0f, 1.0f);
 }
-__device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f));
-}
+__device__ __forceinline__ float gelu_erf(float x) { return x * norm_cdf(x); }
 // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
 __device__ __forceinline__ float gelu_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752f));
-  return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+  return norm_cdf(x) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 
 // keep / (1 - p) factors of the 16 consecutive columns nb .. nb + 15 of row m
 __device__ __forceinline__ void drop_factors16(const bd_drop_args& d, int m, int nb, float (&f)[16]) {
 #pragma unroll
-  for (int j4 = 0; j4 < 4; ++j4) {
-    const bd_philox_out w = bd_drop_words(d, (uint32_t)m, (uint32_t)(nb >> 2) + j4);
+  for (int j8 = 0; j8 < 2; ++j8) {
+    const bd_philox_out w = bd_drop_block(d, (uint32_t)m, (uint32_t)(nb >> 3) + j8);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) f[4 * j4 + r] = bd_drop_factor(d, w.v[r]);
+    for (int r = 0; r < 8; ++r) f[8 * j8 + r] = bd_drop_factor(d, w, r);
   }
 }
 

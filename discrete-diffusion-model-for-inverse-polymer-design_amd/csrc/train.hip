@@ -578,9 +578,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned shor
         const int kb = 32 * s4 + 8 * g + 4 * half;
         const unsigned int m4 = *(const unsigned int*)(Ms + kb);
         if (DROP) {   // dP = (dO V^T) * keep / (1 - p)
-          const bd_philox_out w = bd_drop_words(drop, (uint32_t)(((size_t)b * H + h) * L + qr), (uint32_t)((kt0 + kb) >> 2));
+          const bd_philox_out w = bd_drop_block(drop, (uint32_t)(((size_t)b * H + h) * L + qr), (uint32_t)((kt0 + kb) >> 3));
 #pragma unroll
-          for (int r = 0; r < 4; ++r) dp[r] *= bd_drop_factor(drop, w.v[r]);
+          for (int r = 0; r < 4; ++r) dp[r] *= bd_drop_factor(drop, w, 4 * half + r);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -666,15 +666,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const unsigned sho
     }
     __syncthreads();
     // keep decisions of the lane's key against this lane's 32 queries of the tile, one Philox block
-    // per query (the block holds four neighbouring KEYS); a rolled loop keeps the registers free
+    // per query (the block holds eight neighbouring KEYS); a rolled loop keeps the registers free
     uint32_t keepbits = 0u;
     if (DROP) {
       const uint32_t prow0 = (uint32_t)(((size_t)b * H + h) * L + qt0 + 8 * g);
 #pragma nounroll
       for (int i = 0; i < 32; ++i) {
-        const bd_philox_out w = bd_drop_words(drop, prow0 + 32 * (i >> 3) + (i & 7), (uint32_t)(kr >> 2));
-        const uint32_t lo = (kr & 1) ? w.v[1] : w.v[0], hi = (kr & 1) ? w.v[3] : w.v[2];
-        keepbits |= (uint32_t)(((kr & 2) ? hi : lo) >= drop.thr) << i;
+        const bd_philox_out w = bd_drop_block(drop, prow0 + 32 * (i >> 3) + (i & 7), (uint32_t)(kr >> 3));
+        const uint32_t lo = (kr & 2) ? w.v[1] : w.v[0], hi = (kr & 2) ? w.v[3] : w.v[2];
+        const uint32_t word = (kr & 4) ? hi : lo;
+        keepbits |= (uint32_t)(((word >> (16 * (kr & 1))) & 0xffffu) >= drop.thr) << i;
       }
     }
     bf16x8 pf[4], dsf[4];

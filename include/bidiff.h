@@ -232,10 +232,11 @@ int bd_collate_batch(const void* tokens_u16, const long long* offsets, const lon
 
 /* Training dropout (nn.Dropout / SDPA dropout_p, src/model/backbone.py:30,65,93,98,100,185,247).
  * Keep decisions are a pure function of (seed, step, site, row, column): one Philox4x32-10 block
- * with counter (column / 4, row, site, step) and key = seed holds the 32-bit words of four
- * neighbouring columns; an element is kept iff its word >= floor(p * 2^32) and is then scaled by
- * 1 / (1 - p). Forward and backward kernels regenerate the decisions, nothing is stored; a caller
- * bumps `step` once per forward pass. A null bd_dropout or p == 0 is the identity.
+ * with counter (column / 8, row, site, step) and key = seed serves eight neighbouring columns; column
+ * c takes the low (c even) or high (c odd) 16 bits of word (c % 8) / 2 and is kept iff that number
+ * >= floor(p * 2^16), then scaled by 1 / (1 - p). Forward and backward kernels regenerate the
+ * decisions, nothing is stored; a caller bumps `step` once per forward pass. A null bd_dropout or
+ * p < 2^-16 is the identity.
  * Sites of the denoiser (rows x columns): 0 = embedding sum [B*L, d]; for block i:
  * 4 i + 1 = attention probabilities [(b H + h) L + query, key], 4 i + 2 = GELU output [B*L, F],
  * 4 i + 3 = fc2 output [B*L, d]. */

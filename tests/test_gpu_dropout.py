@@ -1,5 +1,5 @@
 """GPU parity of training dropout. The kernels draw their keep decisions from a counter-based
-stream (Philox block per (site, row, 4 columns)); the CPU oracle evaluates the same stream, so
+stream (Philox block per (site, row, 8 columns)); the CPU oracle evaluates the same stream, so
 both sides drop the SAME elements and the comparison is as tight as without dropout. The keep
 pattern itself is checked bit-exactly; values to the bf16 / fp32 bars of the dropout-free tests."""
 import ctypes as C
