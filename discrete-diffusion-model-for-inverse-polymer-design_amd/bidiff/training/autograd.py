@@ -10,6 +10,7 @@ fc2 output :100) are applied inside the kernels from a counter-based decision st
 backward kernels regenerate; no mask tensor exists.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -18,6 +19,18 @@ from .. import _lib
 
 def _s():
     return _lib.stream_handle()
+
+
+_SIDE = {}
+
+
+def _side_stream(dev):
+    """Second HIP stream of the device for the weight-gradient GEMMs (``BD_ASYNC_WGRAD=0`` turns it off)."""
+    if os.environ.get("BD_ASYNC_WGRAD", "1") == "0":
+        return None
+    if dev not in _SIDE:
+        _SIDE[dev] = torch.cuda.Stream(device=dev)
+    return _SIDE[dev]
 
 
 def _ck(rc, what):
@@ -286,9 +299,34 @@ class _BackboneFn(torch.autograd.Function):
         _ln_bwd(dh_buf, ctx.x_last, ctx.stf, model.final_norm.weight, None, dx, gbuf(model.final_norm.weight),
                 gbuf(model.final_norm.bias), M, d)
 
-        dy = torch.empty(M, d, dtype=bf, device=dev)
+        dy = torch.empty(M, d, dtype=bf, device=dev)        # gradient of the feed-forward branch output
+        dy2 = torch.empty(M, d, dtype=bf, device=dev)       # gradient of the attention branch output
         du = torch.empty(M, F, dtype=bf, device=dev)
         aw, dh, dhp, padded = tw.aw, tw.dh, tw.dhp, tw.dhp != tw.dh
+
+        # The weight-gradient GEMMs feed nothing further down the chain, so they run on a second stream
+        # beside the data-gradient chain (their atomic drains and tails overlap with its kernels). A
+        # buffer they read is not overwritten before they are done (event per buffer).
+        main = torch.cuda.current_stream(dev)
+        side = None if padded else _side_stream(dev)
+        last_read = {}
+
+        def wgrad_side(dY, X, dW, N, K, db):
+            if side is None:
+                return _wgrad(dY, X, dW, M, N, K, db=db)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                _wgrad(dY, X, dW, M, N, K, db=db)
+                done = torch.cuda.Event()
+                done.record(side)
+            last_read[dY.data_ptr()] = done
+
+        def before_write(buf):
+            ev = last_read.pop(buf.data_ptr(), None)
+            if ev is not None:
+                main.wait_event(ev)
         datt = torch.empty(M, aw, dtype=bf, device=dev)
         dqkv = torch.empty(M, 3 * aw, dtype=bf, device=dev)
         delta = torch.empty(B, H, L, device=dev)
@@ -296,27 +334,31 @@ class _BackboneFn(torch.autograd.Function):
                                  reversed(ctx.saved)):
             a = blk.attn
             # x_out = x_mid + drop(fc2(drop(gelu(fc1(LN2(x_mid))))))
+            before_write(dy)
             _to_bf16(dx, dy, drop, 4 * li + 3)
-            _wgrad(dy, s["a"], gbuf(blk.ffn.fc2.weight), M, d, F, db=gbuf(blk.ffn.fc2.bias))
+            wgrad_side(dy, s["a"], gbuf(blk.ffn.fc2.weight), d, F, gbuf(blk.ffn.fc2.bias))
+            before_write(du)
             _gemm(dy, w["w2T"], None, du, M, F, F, d, F, 4, aux_in=s["u"], drop=drop, site=4 * li + 2)
-            _wgrad(du, s["h2"], gbuf(blk.ffn.fc1.weight), M, F, d, db=gbuf(blk.ffn.fc1.bias))
+            wgrad_side(du, s["h2"], gbuf(blk.ffn.fc1.weight), F, d, gbuf(blk.ffn.fc1.bias))
             _gemm(du, w["w1T"], None, dh_buf, M, d, d, F, d, 0)
             _ln_bwd(dh_buf, s["x_mid"], s["st2"], blk.norm2.weight, dx, dx, gbuf(blk.norm2.weight), gbuf(blk.norm2.bias), M, d)
             # x_mid = x_in + out_proj(attention(qkv(LN1(x_in))))
-            _to_bf16(dx, dy)
+            before_write(dy2)
+            _to_bf16(dx, dy2)
             if not padded:
-                _wgrad(dy, s["att"], gbuf(a.out_proj.weight), M, d, d, db=gbuf(a.out_proj.bias))
+                wgrad_side(dy2, s["att"], gbuf(a.out_proj.weight), d, d, gbuf(a.out_proj.bias))
             else:       # gradient of the zero-padded weight, real columns added to the parameter's
                 tmp = zeros(d, aw)
-                _wgrad(dy, s["att"], tmp, M, d, aw, db=gbuf(a.out_proj.bias))
+                _wgrad(dy2, s["att"], tmp, M, d, aw, db=gbuf(a.out_proj.bias))
                 gbuf(a.out_proj.weight).view(d, H, dh).add_(tmp.view(d, H, dhp)[:, :, :dh])
-            _gemm(dy, w["woT"], None, datt, M, aw, aw, d, aw, 0)
+            _gemm(dy2, w["woT"], None, datt, M, aw, aw, d, aw, 0)
+            before_write(dqkv)
             _ck(lib.bd_attention_bwd_drop(_lib.ptr(s["qkv"]), _lib.ptr(keymask), _lib.ptr(s["att"]), _lib.ptr(datt),
                                           _lib.ptr(s["lse"]), _lib.ptr(delta), _lib.ptr(dqkv), B, L, H, aw // H,
                                           _dp(drop), 4 * li + 1, _s()), "bd_attention_bwd")
             projs = (a.q_proj, a.k_proj, a.v_proj)
             if not padded:      # the three row segments of the stacked gradient, one launch
-                _wgrad(dqkv, s["h1"], [gbuf(pr.weight) for pr in projs], M, 3 * aw, d, db=[gbuf(pr.bias) for pr in projs])
+                wgrad_side(dqkv, s["h1"], [gbuf(pr.weight) for pr in projs], 3 * aw, d, [gbuf(pr.bias) for pr in projs])
             else:   # rows of the padded projections; the q rows were scaled by qfix in the forward
                 tw_, tb_ = zeros(3, aw, d), zeros(3, aw)
                 _wgrad(dqkv, s["h1"], [tw_[0], tw_[1], tw_[2]], M, 3 * aw, d, db=[tb_[0], tb_[1], tb_[2]])
@@ -332,6 +374,8 @@ class _BackboneFn(torch.autograd.Function):
                              _lib.ptr(gbuf(model.position_embedding.weight)),
                              _lib.ptr(gbuf(model.timestep_embedding.weight)), B, L, d, int(model.pad_token_id), _s()),
             "bd_embed_bwd")
+        if side is not None:
+            main.wait_stream(side)       # every gradient is complete before autograd / the optimizer go on
         out = [None, None, None, None]
         for p in params:
             g = grads.get(p)
