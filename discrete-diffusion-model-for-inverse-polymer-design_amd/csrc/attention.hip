@@ -71,9 +71,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
 
   for (int kt0 = 0; kt0 < L; kt0 += KT) {
     if (kt0 > 0) __syncthreads();
-    // ---- stage K, V (zero rows past L) and the key mask tile
+    // ---- stage the key mask tile, then K, V of the 32-key groups that hold a visible key (a group
+    //      of masked keys has probability exactly 0: it is neither loaded nor multiplied)
+    if (tid < KT) {
+      const int key = kt0 + tid;
+      unsigned char mv = 0;
+      if (key < L) mv = keymask ? (keymask[(size_t)b * L + key] != 0) : 1;
+      Ms[tid] = mv;
+    }
+    __syncthreads();
+    bool live[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const u32x4 m0 = *(const u32x4*)(Ms + 32 * s4), m1 = *(const u32x4*)(Ms + 32 * s4 + 16);
+      live[s4] = ((m0[0] | m0[1] | m0[2] | m0[3] | m1[0] | m1[1] | m1[2] | m1[3]) != 0u);
+    }
     for (int idx = tid; idx < KT * CPR; idx += 256) {
       const int row = idx / CPR, ch = idx % CPR;
+      if (!live[row >> 5]) continue;
       const int key = kt0 + row;
       u32x4 kv = (u32x4){0u, 0u, 0u, 0u}, vv = (u32x4){0u, 0u, 0u, 0u};
       if (key < L) {
@@ -85,12 +100,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
       *(u32x4*)(Ks + off) = kv;
       *(u32x4*)(Vs + off) = vv;
     }
-    if (tid < KT) {
-      const int key = kt0 + tid;
-      unsigned char mv = 0;
-      if (key < L) mv = keymask ? (keymask[(size_t)b * L + key] != 0) : 1;
-      Ms[tid] = mv;
-    }
     __syncthreads();
 
     // ---- S^T tiles: s[tile][r] <-> key_local = 32 (tile>>1) + 8 g + 4 (tile&1) + r, query c
@@ -98,11 +107,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
 #pragma unroll
     for (int tile = 0; tile < 8; ++tile) {
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const int krow = 32 * (tile >> 1) + 8 * (c >> 2) + 4 * (tile & 1) + (c & 3);
+      if (live[tile >> 1]) {
+        const int krow = 32 * (tile >> 1) + 8 * (c >> 2) + 4 * (tile & 1) + (c & 3);
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 a = *(const bf16x8*)(Ks + kv_off(krow, 4 * ks + g));
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], acc, 0, 0, 0);
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8 a = *(const bf16x8*)(Ks + kv_off(krow, 4 * ks + g));
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], acc, 0, 0, 0);
+        }
       }
       s[tile] = acc;
     }
@@ -179,6 +190,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
     for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
+        if (!live[s4]) continue;
         const int r0 = 32 * s4 + 8 * g + q4;
         const int ch = 2 * dt + (p4 >> 1);
         const s16x4 lo = lds_read_tr(Vs + kv_off(r0, ch) + 8 * (p4 & 1));

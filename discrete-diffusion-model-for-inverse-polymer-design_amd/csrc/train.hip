@@ -491,10 +491,11 @@ constexpr int AROW = 256;   // LDS row stride in bytes
 
 template <int DH>
 __device__ __forceinline__ void stage_rows(unsigned char* dst, const unsigned short* src, size_t row_stride,
-                                           int first, int limit, int tid) {
+                                           int first, int limit, int tid, unsigned groups = 0xfu) {
   constexpr int CPR = DH / 8;
   for (int idx = tid; idx < AT * CPR; idx += 256) {
     const int row = idx / CPR, ch = idx % CPR;
+    if (!((groups >> (row >> 5)) & 1u)) continue;      // 32-row group not wanted
     u32x4 v = (u32x4){0u, 0u, 0u, 0u};
     if (first + row < limit) v = *(const u32x4*)(src + (size_t)(first + row) * row_stride + ch * 8);
     *(u32x4*)(dst + tile_off(row, ch)) = v;
@@ -553,17 +554,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned shor
 
   for (int kt0 = 0; kt0 < L; kt0 += AT) {
     if (kt0 > 0) __syncthreads();
-    stage_rows<DH>(Ks, qkv + (size_t)b * L * row3 + d + (size_t)h * DH, row3, kt0, L, tid);
-    stage_rows<DH>(Vs, qkv + (size_t)b * L * row3 + 2 * d + (size_t)h * DH, row3, kt0, L, tid);
     if (tid < AT) {
       const int key = kt0 + tid;
       Ms[tid] = key < L ? (keymask ? (keymask[(size_t)b * L + key] != 0) : 1) : 0;
     }
     __syncthreads();
+    // 32-key groups without a visible key have P = 0 and dS = 0: not loaded, not multiplied
+    unsigned live = 0u;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const u32x4 m0 = *(const u32x4*)(Ms + 32 * s4), m1 = *(const u32x4*)(Ms + 32 * s4 + 16);
+      if ((m0[0] | m0[1] | m0[2] | m0[3] | m1[0] | m1[1] | m1[2] | m1[3]) != 0u) live |= 1u << s4;
+    }
+    stage_rows<DH>(Ks, qkv + (size_t)b * L * row3 + d + (size_t)h * DH, row3, kt0, L, tid, live);
+    stage_rows<DH>(Vs, qkv + (size_t)b * L * row3 + 2 * d + (size_t)h * DH, row3, kt0, L, tid, live);
+    __syncthreads();
     bf16x8 dsf[4];
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
       bf16x8 frag;
+      if (!((live >> s4) & 1u)) continue;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int krow = 32 * s4 + 8 * (c >> 2) + 4 * half + (c & 3);
@@ -596,6 +606,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned shor
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
+        if (!((live >> s4) & 1u)) continue;
         const int r0 = 32 * s4 + 8 * g + q4, ch = 2 * dt + (p4 >> 1);
         union { struct { s16x4 a, b; } s; bf16x8 v; } u;
         u.s.a = lds_read_tr(Ks + tile_off(r0, ch) + 8 * (p4 & 1));
@@ -640,6 +651,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const unsigned sho
   kr = kok ? kr : L - 1;
   const size_t tok = (size_t)b * L + kr;
   const bool vis = kok && (keymask ? keymask[tok] != 0 : true);
+  if (!__syncthreads_or(vis)) {       // no visible key in this workgroup: dK = dV = 0
+    if (kok) {
+      unsigned short* op = dqkv + tok * row3 + d + (size_t)h * DH + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        *(u32x2*)(op + 16 * dt) = (u32x2){0u, 0u};
+        *(u32x2*)(op + d + 16 * dt) = (u32x2){0u, 0u};
+      }
+    }
+    return;
+  }
+  const bool wave_live = __any(vis);   // a wave of masked keys still stages and synchronises, but multiplies nothing
 
   bf16x8 kf[KS], vf[KS];
   {
@@ -665,6 +688,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const unsigned sho
       Dl[tid] = q < L ? delta[((size_t)b * H + h) * L + q] : 0.f;
     }
     __syncthreads();
+    if (!wave_live) continue;
     // keep decisions of the lane's key against this lane's 32 queries of the tile, one Philox block
     // per query (the block holds eight neighbouring KEYS); a rolled loop keeps the registers free
     uint32_t keepbits = 0u;
