@@ -53,9 +53,11 @@ def _ln(x, g, b, out_bf16, stats, M, d, eps):
                                 M, d, eps, _s()), "bd_layernorm")
 
 
-def _ln_bwd(dy, x, stats, g, dres, dx, dg, db, M, d):
-    _ck(_lib.lib().bd_layernorm_bwd(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(stats), _lib.ptr(g), _lib.ptr(dres),
-                                    _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), M, d, _s()), "bd_layernorm_bwd")
+def _ln_bwd(dy, x, stats, g, dres, dx, dg, db, M, d, dx_bf16=None, drop=None, site=0):
+    """dx (fp32) and optionally its bf16 copy (dropped at ``site`` when ``drop`` is given) in one pass."""
+    _ck(_lib.lib().bd_layernorm_bwd_cast(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(stats), _lib.ptr(g), _lib.ptr(dres),
+                                         _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), M, d, _lib.ptr(dx_bf16),
+                                         _dp(drop if dx_bf16 is not None else None), site, _s()), "bd_layernorm_bwd")
 
 
 def _wgrad(dY, X, dW, M, N, K, db=None):
@@ -296,11 +298,15 @@ class _BackboneFn(torch.autograd.Function):
         dh_buf = torch.empty(M, d, dtype=bf, device=dev)
         _gemm(dl, tw.woutT, None, dh_buf, M, d, d, tw.vpad, d, 0)
         dx = torch.empty(M, d, device=dev)
-        _ln_bwd(dh_buf, ctx.x_last, ctx.stf, model.final_norm.weight, None, dx, gbuf(model.final_norm.weight),
-                gbuf(model.final_norm.bias), M, d)
-
+        # every LayerNorm backward also emits the bf16 gradient the next branch reads (with the fc2-output
+        # dropout of that branch folded in), so dx is not read again just to be cast
+        n_layers = len(model.layers)
         dy = torch.empty(M, d, dtype=bf, device=dev)        # gradient of the feed-forward branch output
         dy2 = torch.empty(M, d, dtype=bf, device=dev)       # gradient of the attention branch output
+        _ln_bwd(dh_buf, ctx.x_last, ctx.stf, model.final_norm.weight, None, dx, gbuf(model.final_norm.weight),
+                gbuf(model.final_norm.bias), M, d, dx_bf16=dy if n_layers else None, drop=drop,
+                site=max(0, 4 * (n_layers - 1) + 3))
+
         du = torch.empty(M, F, dtype=bf, device=dev)
         aw, dh, dhp, padded = tw.aw, tw.dh, tw.dhp, tw.dhp != tw.dh
 
@@ -334,17 +340,15 @@ class _BackboneFn(torch.autograd.Function):
                                  reversed(ctx.saved)):
             a = blk.attn
             # x_out = x_mid + drop(fc2(drop(gelu(fc1(LN2(x_mid))))))
-            before_write(dy)
-            _to_bf16(dx, dy, drop, 4 * li + 3)
             wgrad_side(dy, s["a"], gbuf(blk.ffn.fc2.weight), d, F, gbuf(blk.ffn.fc2.bias))
             before_write(du)
             _gemm(dy, w["w2T"], None, du, M, F, F, d, F, 4, aux_in=s["u"], drop=drop, site=4 * li + 2)
             wgrad_side(du, s["h2"], gbuf(blk.ffn.fc1.weight), F, d, gbuf(blk.ffn.fc1.bias))
             _gemm(du, w["w1T"], None, dh_buf, M, d, d, F, d, 0)
-            _ln_bwd(dh_buf, s["x_mid"], s["st2"], blk.norm2.weight, dx, dx, gbuf(blk.norm2.weight), gbuf(blk.norm2.bias), M, d)
-            # x_mid = x_in + out_proj(attention(qkv(LN1(x_in))))
             before_write(dy2)
-            _to_bf16(dx, dy2)
+            _ln_bwd(dh_buf, s["x_mid"], s["st2"], blk.norm2.weight, dx, dx, gbuf(blk.norm2.weight), gbuf(blk.norm2.bias), M, d,
+                    dx_bf16=dy2)
+            # x_mid = x_in + out_proj(attention(qkv(LN1(x_in))))
             if not padded:
                 wgrad_side(dy2, s["att"], gbuf(a.out_proj.weight), d, d, gbuf(a.out_proj.bias))
             else:       # gradient of the zero-padded weight, real columns added to the parameter's
@@ -367,7 +371,10 @@ class _BackboneFn(torch.autograd.Function):
                     gbuf(proj.weight).view(H, dh, d).add_(tw_[i].view(H, dhp, d)[:, :dh], alpha=f)
                     gbuf(proj.bias).view(H, dh).add_(tb_[i].view(H, dhp)[:, :dh], alpha=f)
             _gemm(dqkv, w["wqkvT"], None, dh_buf, M, d, d, 3 * aw, d, 0)
-            _ln_bwd(dh_buf, s["x_in"], s["st1"], blk.norm1.weight, dx, dx, gbuf(blk.norm1.weight), gbuf(blk.norm1.bias), M, d)
+            if li > 0:
+                before_write(dy)
+            _ln_bwd(dh_buf, s["x_in"], s["st1"], blk.norm1.weight, dx, dx, gbuf(blk.norm1.weight), gbuf(blk.norm1.bias), M, d,
+                    dx_bf16=dy if li > 0 else None, drop=drop, site=max(0, 4 * (li - 1) + 3))
         if drop is not None:
             _ck(lib.bd_dropout_f32(_lib.ptr(dx), _lib.ptr(dx), M, d, _dp(drop), 0, _s()), "bd_dropout_f32")
         _ck(lib.bd_embed_bwd(_lib.ptr(dx), _lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(gbuf(model.token_embedding.weight)),

@@ -104,7 +104,8 @@ __global__ __launch_bounds__(512) void layernorm_bwd_kernel(const unsigned short
                                                             const float* __restrict__ gamma,
                                                             const float* dres, float* dx,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int M, int d) {
+                                                            int M, int d, unsigned short* __restrict__ dx_bf16,
+                                                            bd_drop_args drop) {
   constexpr int RPW = 16;
   extern __shared__ float red[];   // [2][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -163,6 +164,17 @@ __global__ __launch_bounds__(512) void layernorm_bwd_kernel(const unsigned short
           o[0] += r[0]; o[1] += r[1]; o[2] += r[2]; o[3] += r[3];
         }
         ((f32x4*)(dx + (size_t)row * d))[i] = o;
+        if (dx_bf16 != nullptr) {      // the next branch's incoming gradient: bf16 copy, optionally dropped
+          if (drop.thr != 0u) {
+            const bd_philox_out w = bd_drop_block(drop, (uint32_t)row, (uint32_t)(i >> 1));
+            const int j0 = 4 * (i & 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] *= bd_drop_factor(drop, w, j0 + e);
+          }
+          u32x2 pk;
+          pk[0] = bd_pack_bf16x2(o[0], o[1]); pk[1] = bd_pack_bf16x2(o[2], o[3]);
+          *(u32x2*)(dx_bf16 + (size_t)row * d + 4 * i) = pk;
+        }
       }
     }
   }
@@ -971,22 +983,34 @@ extern "C" int bd_masked_ce_bwd(const float* logits, const long long* targets, c
   return bd_check_launch("bd_masked_ce_bwd");
 }
 
-extern "C" int bd_layernorm_bwd(const void* dy_bf16, const float* x, const float* stats, const float* gamma,
-                                const float* dres, float* dx, float* dgamma, float* dbeta, int M, int d,
-                                void* stream) {
+extern "C" int bd_layernorm_bwd_cast(const void* dy_bf16, const float* x, const float* stats, const float* gamma,
+                                     const float* dres, float* dx, float* dgamma, float* dbeta, int M, int d,
+                                     void* dx_bf16, const bd_dropout* drop, unsigned site, void* stream) {
   BD_REQUIRE(dy_bf16 && x && stats && gamma && dx && dgamma && dbeta, "bd_layernorm_bwd: null operand");
   BD_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 4096, "bd_layernorm_bwd: bad shape M=%d d=%d", M, d);
+  bd_drop_args da;
+  BD_REQUIRE(bd_drop_make(drop, site, &da), "bd_layernorm_bwd: dropout p=%g outside [0, 1)", (double)drop->p);
+  BD_REQUIRE(da.thr == 0u || (dx_bf16 != nullptr && d % 8 == 0), "bd_layernorm_bwd: dropout applies to the bf16 output (d %% 8 == 0)");
   dim3 grid((M + 127) / 128), block(512);
   const size_t lds = 2 * (size_t)d * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   const unsigned short* dy = (const unsigned short*)dy_bf16;
+  unsigned short* ob = (unsigned short*)dx_bf16;
   const int nv = (d / 4 + 63) / 64;
-  if (nv <= 1) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, block, lds, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d);
-  else if (nv <= 2) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, block, lds, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d);
-  else if (nv <= 4) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, lds, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d);
-  else if (nv <= 8) hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, block, lds, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d);
-  else hipLaunchKernelGGL(layernorm_bwd_kernel<16>, grid, block, lds, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d);
+#define BD_LNB(NV) hipLaunchKernelGGL(layernorm_bwd_kernel<NV>, grid, block, lds, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d, ob, da)
+  if (nv <= 1) BD_LNB(1);
+  else if (nv <= 2) BD_LNB(2);
+  else if (nv <= 4) BD_LNB(4);
+  else if (nv <= 8) BD_LNB(8);
+  else BD_LNB(16);
+#undef BD_LNB
   return bd_check_launch("bd_layernorm_bwd");
+}
+
+extern "C" int bd_layernorm_bwd(const void* dy_bf16, const float* x, const float* stats, const float* gamma,
+                                const float* dres, float* dx, float* dgamma, float* dbeta, int M, int d,
+                                void* stream) {
+  return bd_layernorm_bwd_cast(dy_bf16, x, stats, gamma, dres, dx, dgamma, dbeta, M, d, nullptr, nullptr, 0u, stream);
 }
 
 // Group count J of the LDS-DMA kernel from a small cost model fitted to measurements (microseconds):

@@ -283,6 +283,13 @@ int bd_masked_ce_bwd(const float* logits, const long long* targets, const unsign
 int bd_layernorm_bwd(const void* dy_bf16, const float* x, const float* stats, const float* gamma,
                      const float* dres, float* dx, float* dgamma, float* dbeta, int M, int d, void* stream);
 
+/* The same, also writing dx rounded to bf16 (dx_bf16 [M, d]; what the next branch's GEMMs read),
+ * with optional dropout of that copy: dx_bf16 = bf16(dx * keep / (1 - p)) at (row m, column n) of `site`
+ * (the backward of the dropout after fc2, src/model/backbone.py:100). */
+int bd_layernorm_bwd_cast(const void* dy_bf16, const float* x, const float* stats, const float* gamma,
+                          const float* dres, float* dx, float* dgamma, float* dbeta, int M, int d,
+                          void* dx_bf16, const bd_dropout* drop, unsigned site, void* stream);
+
 /* dW[N,K] += dY[M,N]^T * X[M,K] (bf16 in, fp32 accumulate with atomics); N, K multiples of 128.
  * (autograd of nn.Linear weights, src/model/backbone.py:25-28,91-92,195). */
 int bd_gemm_wgrad_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, int M, int N, int K,
