@@ -43,6 +43,14 @@ BD_HD float bd_uniform_select(uint64_t seed, uint32_t seq, uint32_t t, uint32_t 
   bd_philox_out o = bd_philox4x32_10(pos, seq, t, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
   return bd_u01(o.v[0]);
 }
+// Corruption stream q(x_t | x_0): one block per four neighbouring positions, counter
+// (pos / 4, sequence index, t, 2^31), word pos % 4 (lanes below 2^31 belong to the sampler).
+BD_HD bd_philox_out bd_corrupt_block(uint64_t seed, uint32_t seq, uint32_t t, uint32_t pos4) {
+  return bd_philox4x32_10(pos4, seq, t, 0x80000000u, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+BD_HD float bd_uniform_corrupt(uint64_t seed, uint32_t seq, uint32_t t, uint32_t pos) {
+  return bd_u01(bd_corrupt_block(seed, seq, t, pos >> 2).v[pos & 3u]);
+}
 BD_HD float bd_uniform_token(uint64_t seed, uint32_t seq, uint32_t t, uint32_t pos, uint32_t v) {
   bd_philox_out o = bd_philox4x32_10(pos, seq, t, 1u + (v >> 2), (uint32_t)seed, (uint32_t)(seed >> 32));
   return bd_u01(o.v[v & 3u]);

@@ -232,13 +232,62 @@ __global__ __launch_bounds__(256) void corrupt_kernel(const long long* __restric
   const long long t = tsteps[b];
   const float p = schedule[t];
   const float u = uniforms ? uniforms[i]
-                           : bd_uniform_select(seed, (uint32_t)(b + seq_offset), (uint32_t)t, (uint32_t)l);
+                           : bd_uniform_corrupt(seed, (uint32_t)(b + seq_offset), (uint32_t)t, (uint32_t)l);
   bool m = u < p;
   m = m && (attn ? (attn[i] == 1) : (id != pad_id));
   if (has_bos) m = m && (id != bos_id);
   if (has_eos) m = m && (id != eos_id);
   noisy[i] = m ? (long long)mask_id : id;
   indicator[i] = m ? 1 : 0;
+}
+
+// The same for L % 4 == 0: a thread owns four neighbouring positions of one sequence (one Philox
+// block, 32-byte loads and stores of the int64 ids, one 4-byte store of the indicator).
+typedef __attribute__((ext_vector_type(2))) long long i64x2;
+__global__ __launch_bounds__(256) void corrupt4_kernel(const long long* __restrict__ ids,
+                                                       const long long* __restrict__ attn,
+                                                       const long long* __restrict__ tsteps,
+                                                       const float* __restrict__ schedule,
+                                                       const float* __restrict__ uniforms,
+                                                       long long* __restrict__ noisy,
+                                                       unsigned char* __restrict__ indicator,
+                                                       long long n4, int L4, int mask_id, int pad_id,
+                                                       int bos_id, int eos_id, int has_bos, int has_eos,
+                                                       unsigned long long seed, long long seq_offset) {
+  const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (g >= n4) return;
+  const long long b = g / L4;
+  const int l4 = (int)(g - b * L4);
+  const long long t = tsteps[b];
+  const float p = schedule[t];
+  long long id[4], am[4];
+  *(i64x2*)(id) = ((const i64x2*)ids)[2 * g];
+  *(i64x2*)(id + 2) = ((const i64x2*)ids)[2 * g + 1];
+  if (attn) {
+    *(i64x2*)(am) = ((const i64x2*)attn)[2 * g];
+    *(i64x2*)(am + 2) = ((const i64x2*)attn)[2 * g + 1];
+  }
+  float u[4];
+  if (uniforms) {
+    const f32x4 uv = ((const f32x4*)uniforms)[g];
+    u[0] = uv[0]; u[1] = uv[1]; u[2] = uv[2]; u[3] = uv[3];
+  } else {
+    const bd_philox_out w = bd_corrupt_block(seed, (uint32_t)(b + seq_offset), (uint32_t)t, (uint32_t)l4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) u[e] = bd_u01(w.v[e]);
+  }
+  unsigned int flags = 0u;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    bool m = u[e] < p;
+    m = m && (attn ? (am[e] == 1) : (id[e] != pad_id));
+    if (has_bos) m = m && (id[e] != bos_id);
+    if (has_eos) m = m && (id[e] != eos_id);
+    if (m) { id[e] = (long long)mask_id; flags |= 1u << (8 * e); }
+  }
+  ((i64x2*)noisy)[2 * g] = *(i64x2*)(id);
+  ((i64x2*)noisy)[2 * g + 1] = *(i64x2*)(id + 2);
+  ((unsigned int*)indicator)[g] = flags;
 }
 
 // byte mask from an int64 attention mask (non-zero -> 1)
@@ -342,10 +391,17 @@ extern "C" int bd_corrupt(const long long* ids, const long long* attention_mask,
   BD_REQUIRE(B >= 0 && L >= 0 && schedule_len > 0, "bd_corrupt: bad shape");
   const long long n = (long long)B * L;
   if (n == 0) return BD_OK;
-  hipLaunchKernelGGL(corrupt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     ids, attention_mask, timesteps, schedule, uniforms, noisy_ids, mask_indicator, n, L,
-                     mask_id, pad_id, bos_id, eos_id, bos_id >= 0 ? 1 : 0, eos_id >= 0 ? 1 : 0, seed,
-                     seq_offset);
+  const bool aligned = ((((uintptr_t)ids | (uintptr_t)noisy_ids | (uintptr_t)attention_mask | (uintptr_t)uniforms) & 15u) == 0u) &&
+                       (((uintptr_t)mask_indicator & 3u) == 0u);
+  if (L % 4 == 0 && aligned)
+    hipLaunchKernelGGL(corrupt4_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       ids, attention_mask, timesteps, schedule, uniforms, noisy_ids, mask_indicator, n / 4, L / 4,
+                       mask_id, pad_id, bos_id, eos_id, bos_id >= 0 ? 1 : 0, eos_id >= 0 ? 1 : 0, seed, seq_offset);
+  else
+    hipLaunchKernelGGL(corrupt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       ids, attention_mask, timesteps, schedule, uniforms, noisy_ids, mask_indicator, n, L,
+                       mask_id, pad_id, bos_id, eos_id, bos_id >= 0 ? 1 : 0, eos_id >= 0 ? 1 : 0, seed,
+                       seq_offset);
   return bd_check_launch("bd_corrupt");
 }
 

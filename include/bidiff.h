@@ -206,8 +206,8 @@ int bd_gemm_bf16_aux(const void* A, const void* W, const float* bias, void* out,
 
 /* should_mask = (u < schedule[t[b]]) & (attention_mask == 1, or ids != pad when the mask is
  * null) & ids != bos & ids != eos (bos/eos < 0 = "None"); noisy = mask_id where should_mask.
- * uniforms [B,L] fp32 or null; null draws u from Philox4x32-10 keyed by
- * (seed, seq_offset + b, t[b], l).
+ * uniforms [B,L] fp32 or null; null draws u from Philox4x32-10 with key = seed: word l % 4 of the
+ * block with counter (l / 4, seq_offset + b, t[b], 2^31).
  * replaces DiscreteMaskingDiffusion.forward_process, src/model/diffusion.py:84-127. */
 int bd_corrupt(const long long* ids, const long long* attention_mask, const long long* timesteps,
                const float* schedule, int schedule_len, const float* uniforms,
