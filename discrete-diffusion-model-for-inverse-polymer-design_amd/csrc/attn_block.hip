@@ -96,7 +96,7 @@ int launch_attn(const AttnArgs& a, hipStream_t stream) {
 extern "C" int bd_attn_block_supported(int d, int n_heads, int L) {
   if (n_heads <= 0 || d % n_heads) return 0;
   const int dh = d / n_heads;
-  const bool shape = (d == 384 && dh == 128) || (d == 256 && (dh == 128 || dh == 64)) || (d == 128 && (dh == 64 || dh == 32));
+  const bool shape = (d == 384 && (dh == 128 || dh == 64)) || (d == 256 && (dh == 128 || dh == 64)) || (d == 128 && (dh == 64 || dh == 32));
   return shape && L >= 1 && L <= 128;
 }
 
@@ -132,7 +132,8 @@ extern "C" int bd_attn_block_fused(const float* x, float* out, const void* wpack
   const int dh = d / n_heads;
   void* tok = bd_prof_on() ? bd_prof_begin(stream) : nullptr;
   int rc;
-  if (d == 384) rc = launch_attn<24, 128>(a, stream);
+  if (d == 384 && dh == 128) rc = launch_attn<24, 128>(a, stream);
+  else if (d == 384) rc = launch_attn<24, 64>(a, stream);
   else if (d == 256 && dh == 128) rc = launch_attn<16, 128>(a, stream);
   else if (d == 256) rc = launch_attn<16, 64>(a, stream);
   else if (dh == 64) rc = launch_attn<8, 64>(a, stream);

@@ -195,7 +195,8 @@ extern "C" int bd_backbone_mega(const bd_backbone_desc* desc, const long long* i
   const int d = c.d, dh = d / c.n_heads;
   void* tok = bd_prof_on() ? bd_prof_begin(stream) : nullptr;
   int rc;
-  if (d == 384) rc = launch_mega<24, 128>(a, stream);
+  if (d == 384 && dh == 128) rc = launch_mega<24, 128>(a, stream);
+  else if (d == 384) rc = launch_mega<24, 64>(a, stream);
   else if (d == 256 && dh == 128) rc = launch_mega<16, 128>(a, stream);
   else if (d == 256) rc = launch_mega<16, 64>(a, stream);
   else if (dh == 64) rc = launch_mega<8, 64>(a, stream);

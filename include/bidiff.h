@@ -93,7 +93,7 @@ int bd_ffn_fused(const float* x, float* out, const void* wpack, const float* b1_
  * b_q scaled like the q rows; the k bias is not needed (it shifts all scores of a query equally);
  * the v bias enters through b_o_fold = b_o + Wo * b_v. keymask: byte mask [B, L] or null; a
  * sequence whose keys are all masked gets out = x + b_o (zero attention output, as
- * bd_attention_fwd + out-proj). Supported: (d, head_dim) in {(384,128), (256,128), (256,64),
+ * bd_attention_fwd + out-proj). Supported: (d, head_dim) in {(384,128), (384,64), (256,128), (256,64),
  * (128,64), (128,32)}, L <= 128.
  * Replaces TransformerBlock.forward's  x + attn(ln1(x))  (src/model/backbone.py:126,
  * MultiHeadAttention.forward :38-72). */

@@ -370,7 +370,8 @@ def _attn_block_case(gpu_device, B, L, d, H, masked, seed):
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,L,d,H,masked", [(3, 128, 384, 3, False), (4, 128, 384, 3, True), (5, 100, 384, 3, True),
                                            (2, 1, 384, 3, False), (2, 128, 256, 4, False), (3, 77, 256, 2, True),
-                                           (3, 128, 128, 2, False), (3, 50, 128, 4, True), (300, 128, 384, 3, True)])
+                                           (3, 128, 128, 2, False), (3, 50, 128, 4, True), (300, 128, 384, 3, True),
+                                           (4, 128, 384, 6, True), (3, 90, 384, 6, False)])
 def test_attn_block_fused_matches_fp32_reference(gpu_device, B, L, d, H, masked):
     assert _lib.lib().bd_attn_block_supported(d, H, L) == 1
     out, ref, xs, bo = _attn_block_case(gpu_device, B, L, d, H, masked, seed=B + L + d + H)
