@@ -12,6 +12,7 @@
 #include "bd_common.h"
 #include "bd_prof.h"
 #include "bd_drop.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -93,33 +94,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     if (EPI == EPI_AXPBY_BF16) p.aux_in = (const unsigned short*)p.aux_in + b * p.sOut;
   }
 
-  // XCD-aware, bijective remap: blocks that share an XCD (id % 8) walk a contiguous
-  // run of tiles (n fastest), so the A row-panel is re-read from that XCD's L2.
-  int tile;
-  {
-    const int nwg = p.n_tiles, orig = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  }
-  const int m0 = (tile / p.tiles_n) * BM;
-  const int n0 = (tile % p.tiles_n) * BN;
   const int K = p.K;
+  const int nk = K / BK;
 
-  // ---- staging addresses: thread -> (row = tid/8 + 32 i, 16-byte chunk = tid%8)
+  // ---- staging: thread -> (row = tid/8 + 32 i, 16-byte chunk = tid%8); tile-independent LDS offsets
   const int srow = tid >> 3, sch = tid & 7;
-  const unsigned short* ga[4];
-  const unsigned short* gw[4];
   int offa[4], offw[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = srow + 32 * i;
-    int am = m0 + r; am = am < p.M ? am : p.M - 1;
-    ga[i] = p.A + (size_t)am * K + sch * 8;
-    gw[i] = p.W + (size_t)(n0 + r) * K + sch * 8;
     offa[i] = r * 128 + ((sch ^ swz_a(r)) << 4);
     offw[i] = r * 128 + ((sch ^ swz_w(r)) << 4);
   }
-
   // ---- fragment read offsets (per kk add 64 B chunk pairs through the XOR)
   int fa_row[4], fw_row[4];
 #pragma unroll
@@ -128,20 +114,44 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     fw_row[t] = wn * 64 + 16 * (c >> 2) + 4 * t + (c & 3);     // permuted weight row
   }
 
+  // Persistent workgroups: workgroup w takes the logical ids w, w + gridDim.x, ... (gridDim.x is a
+  // multiple of 8 or the tile count itself, so a logical id keeps the workgroup's XCD = id % 8).
+  // XCD-aware, bijective remap of a logical id: ids that share an XCD walk a contiguous run of tiles
+  // (n fastest), so the A row-panel is re-read from that XCD's L2.
+  const unsigned short* ga[4];
+  const unsigned short* gw[4];
+  int nm0 = 0, nn0 = 0;
+  auto setup = [&](int logical) {     // addresses of a tile's operands; sets nm0 / nn0
+    const int nwg = p.n_tiles;
+    const int q = nwg >> 3, r = nwg & 7, xcd = logical & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (logical >> 3);
+    nm0 = (tile / p.tiles_n) * BM;
+    nn0 = (tile % p.tiles_n) * BN;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = srow + 32 * i;
+      int am = nm0 + rr; am = am < p.M ? am : p.M - 1;
+      ga[i] = p.A + (size_t)am * K + sch * 8;
+      gw[i] = p.W + (size_t)(nn0 + rr) * K + sch * 8;
+    }
+  };
+
+  u32x4 ra[4], rw[4];
+  setup(blockIdx.x);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ra[i] = *(const u32x4*)(ga[i]);
+    rw[i] = *(const u32x4*)(gw[i]);
+  }
+
+  for (int logical = blockIdx.x; logical < p.n_tiles; logical += gridDim.x) {
+  const int m0 = nm0, n0 = nn0;
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  u32x4 ra[4], rw[4];
-  const int nk = K / BK;
-
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    ra[i] = *(const u32x4*)(ga[i]);
-    rw[i] = *(const u32x4*)(gw[i]);
-  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     *(u32x4*)(As + offa[i]) = ra[i];
@@ -186,6 +196,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
       }
     }
     __syncthreads();
+  }
+
+  // the next tile's first operand step is already on its way while this tile's epilogue runs
+  if (logical + (int)gridDim.x < p.n_tiles) {
+    setup(logical + gridDim.x);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = *(const u32x4*)(ga[i]);
+      rw[i] = *(const u32x4*)(gw[i]);
+    }
   }
 
   // ---- epilogue: lane (g, c) holds, for m-tile tm, n = nb + 4 tn + r (16 consecutive)
@@ -291,12 +311,28 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
         if (nb + j < p.n_real) o[nb + j] = v[j];
     }
   }
+  }   // persistent tile loop
+}
+
+// Persistent grid: two workgroups per CU (what the kernel's registers and 64 KB of LDS allow), a
+// multiple of 8 so that logical tile ids keep their XCD; fewer tiles than that: one workgroup each.
+int persistent_grid(int n_tiles) {
+  static int slots = 0;
+  if (!slots) {
+    int dev = 0, ncu = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    slots = 2 * ncu / 8 * 8;
+    if (const char* e = getenv("BD_GEMM_SLOTS")) slots = atoi(e) > 0 ? atoi(e) / 8 * 8 : slots;
+    if (slots < 8) slots = 8;
+  }
+  return n_tiles <= slots ? n_tiles : slots;
 }
 
 template <int EPI, bool DROP = false>
 int launch(const GemmArgs& a, hipStream_t s) {
   void* tok = bd_prof_on() ? bd_prof_begin(s) : nullptr;
-  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, DROP>), dim3(a.n_tiles), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, DROP>), dim3(persistent_grid(a.n_tiles)), dim3(256), 0, s, a);
   if (tok) bd_prof_end(tok, s, 2.0 * (double)a.M * (double)a.n_real * (double)a.K);
   return bd_check_launch("bd_gemm_bf16");
 }
@@ -372,8 +408,9 @@ extern "C" int bd_gemm_bf16_batched(const void* A, const void* W, void* out, con
   bd_drop_make(nullptr, 0u, &a.drop);
   hipStream_t s = (hipStream_t)stream;
   void* tok = bd_prof_on() ? bd_prof_begin(s) : nullptr;
-  if (aux) hipLaunchKernelGGL((gemm_bf16_kernel<EPI_AXPBY_BF16, false>), dim3(a.n_tiles, batch), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((gemm_bf16_kernel<EPI_BIAS_BF16, false>), dim3(a.n_tiles, batch), dim3(256), 0, s, a);
+  const int gx = persistent_grid(a.n_tiles);
+  if (aux) hipLaunchKernelGGL((gemm_bf16_kernel<EPI_AXPBY_BF16, false>), dim3(gx, batch), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((gemm_bf16_kernel<EPI_BIAS_BF16, false>), dim3(gx, batch), dim3(256), 0, s, a);
   if (tok) bd_prof_end(tok, s, 2.0 * batch * (double)M * N * K);
   return bd_check_launch("bd_gemm_bf16_batched");
 }
