@@ -33,7 +33,9 @@ __device__ __forceinline__ s16x4 lds_read_tr(const unsigned char* p) {
       (__attribute__((address_space(3))) s16x4*)(p));
 }
 
-template <int DH, bool DROP>
+// QB = 16-query blocks per wave (1 or 2): with two, every K / V fragment read from LDS feeds two
+// MFMAs, which halves the LDS traffic per flop (the kernel is LDS-bound with one).
+template <int DH, bool DROP, int QB>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* __restrict__ qkv,
                                                           const unsigned char* __restrict__ keymask,
                                                           unsigned short* __restrict__ out,
@@ -53,21 +55,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
   const int b = blockIdx.z, h = blockIdx.y;
   const int d = H * DH;
   const size_t row3 = (size_t)3 * d;
-  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int q0 = blockIdx.x * (64 * QB) + wave * (16 * QB);   // block qb: queries q0 + 16 qb + c
 
-  // Q fragment: lane holds Q[q0 + c][32 ks + 8 g .. +7]
-  bf16x8 qf[KS];
-  {
-    int qr = q0 + c; qr = qr < L ? qr : L - 1;
+  // Q fragments: lane holds Q[q0 + 16 qb + c][32 ks + 8 g .. +7]
+  bf16x8 qf[QB][KS];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    int qr = q0 + 16 * qb + c; qr = qr < L ? qr : L - 1;
     const unsigned short* qp = qkv + ((size_t)b * L + qr) * row3 + (size_t)h * DH + 8 * g;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + 32 * ks);
+    for (int ks = 0; ks < KS; ++ks) qf[qb][ks] = *(const bf16x8*)(qp + 32 * ks);
   }
 
-  f32x4 o[DT];
+  f32x4 o[QB][DT];
+  float m_run[QB], l_run[QB];
 #pragma unroll
-  for (int i = 0; i < DT; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float m_run = -INFINITY, l_run = 0.f;
+  for (int qb = 0; qb < QB; ++qb) {
+    m_run[qb] = -INFINITY; l_run[qb] = 0.f;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[qb][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
 
   for (int kt0 = 0; kt0 < L; kt0 += KT) {
     if (kt0 > 0) __syncthreads();
@@ -102,86 +109,91 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
     }
     __syncthreads();
 
-    // ---- S^T tiles: s[tile][r] <-> key_local = 32 (tile>>1) + 8 g + 4 (tile&1) + r, query c
-    f32x4 s[8];
+    // ---- S^T tiles: s[qb][tile][r] <-> key_local = 32 (tile>>1) + 8 g + 4 (tile&1) + r, query c of block qb
+    f32x4 s[QB][8];
 #pragma unroll
     for (int tile = 0; tile < 8; ++tile) {
-      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) s[qb][tile] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (live[tile >> 1]) {
         const int krow = 32 * (tile >> 1) + 8 * (c >> 2) + 4 * (tile & 1) + (c & 3);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const bf16x8 a = *(const bf16x8*)(Ks + kv_off(krow, 4 * ks + g));
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], acc, 0, 0, 0);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb)
+            s[qb][tile] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[qb][ks], s[qb][tile], 0, 0, 0);
         }
       }
-      s[tile] = acc;
     }
 
-    // ---- masked online softmax along keys (lane-local + the 4 lanes sharing c)
-    float mloc = -INFINITY;
+    bf16x8 pf[QB][4];
 #pragma unroll
-    for (int tile = 0; tile < 8; ++tile) {
-      const int kb = 32 * (tile >> 1) + 8 * g + 4 * (tile & 1);
-      const unsigned int m4 = *(const unsigned int*)(Ms + kb);
+    for (int qb = 0; qb < QB; ++qb) {
+      // ---- masked online softmax along keys (lane-local + the 4 lanes sharing c)
+      float mloc = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const bool vis = ((m4 >> (8 * r)) & 0xffu) != 0u;
-        const float v = vis ? s[tile][r] * scale : -INFINITY;
-        s[tile][r] = v;
-        mloc = fmaxf(mloc, v);
-      }
-    }
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-    const float m_new = fmaxf(m_run, mloc);
-    const bool dead = (m_new == -INFINITY);
-    const float m_use = dead ? 0.f : m_new;
-    const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_use);
-    float psum = 0.f;
-#pragma unroll
-    for (int tile = 0; tile < 8; ++tile)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float pv = __expf(s[tile][r] - m_use);  // exp(-inf) = 0 for masked keys
-        s[tile][r] = pv;
-        psum += pv;
-      }
-    psum += __shfl_xor(psum, 16, 64);
-    psum += __shfl_xor(psum, 32, 64);
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int i = 0; i < DT; ++i) {
-      o[i][0] *= alpha; o[i][1] *= alpha; o[i][2] *= alpha; o[i][3] *= alpha;
-    }
-
-    // ---- dropout of the probabilities (the normaliser l_run keeps every visible key)
-    if (DROP) {
-      const uint32_t prow = (uint32_t)(((size_t)b * H + h) * L + (q0 + c));
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {      // tiles 2 s4, 2 s4 + 1 = keys key0 .. key0 + 7: one block
-        const int key0 = kt0 + 32 * s4 + 8 * g;
-        const bd_philox_out w = bd_drop_block(drop, prow, (uint32_t)(key0 >> 3));
+      for (int tile = 0; tile < 8; ++tile) {
+        const int kb = 32 * (tile >> 1) + 8 * g + 4 * (tile & 1);
+        const unsigned int m4 = *(const unsigned int*)(Ms + kb);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          s[2 * s4][r] *= bd_drop_factor(drop, w, r);
-          s[2 * s4 + 1][r] *= bd_drop_factor(drop, w, 4 + r);
+          const bool vis = ((m4 >> (8 * r)) & 0xffu) != 0u;
+          const float v = vis ? s[qb][tile][r] * scale : -INFINITY;
+          s[qb][tile][r] = v;
+          mloc = fmaxf(mloc, v);
         }
       }
-    }
-
-    // ---- P^T fragments: k-step s4 covers keys 32 s4 + 8 g + j = tiles (2 s4, 2 s4 + 1)
-    bf16x8 pf[4];
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      const float m_new = fmaxf(m_run[qb], mloc);
+      const bool dead = (m_new == -INFINITY);
+      const float m_use = dead ? 0.f : m_new;
+      const float alpha = (m_run[qb] == -INFINITY) ? 0.f : __expf(m_run[qb] - m_use);
+      float psum = 0.f;
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      bf16x8 t;
+      for (int tile = 0; tile < 8; ++tile)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        t[r] = (__bf16)s[2 * s4][r];
-        t[4 + r] = (__bf16)s[2 * s4 + 1][r];
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __expf(s[qb][tile][r] - m_use);  // exp(-inf) = 0 for masked keys
+          s[qb][tile][r] = pv;
+          psum += pv;
+        }
+      psum += __shfl_xor(psum, 16, 64);
+      psum += __shfl_xor(psum, 32, 64);
+      l_run[qb] = l_run[qb] * alpha + psum;
+      m_run[qb] = m_new;
+#pragma unroll
+      for (int i = 0; i < DT; ++i) {
+        o[qb][i][0] *= alpha; o[qb][i][1] *= alpha; o[qb][i][2] *= alpha; o[qb][i][3] *= alpha;
       }
-      pf[s4] = t;
+
+      // ---- dropout of the probabilities (the normaliser l_run keeps every visible key)
+      if (DROP) {
+        const uint32_t prow = (uint32_t)(((size_t)b * H + h) * L + (q0 + 16 * qb + c));
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {      // tiles 2 s4, 2 s4 + 1 = keys key0 .. key0 + 7: one block
+          const int key0 = kt0 + 32 * s4 + 8 * g;
+          const bd_philox_out w = bd_drop_block(drop, prow, (uint32_t)(key0 >> 3));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            s[qb][2 * s4][r] *= bd_drop_factor(drop, w, r);
+            s[qb][2 * s4 + 1][r] *= bd_drop_factor(drop, w, 4 + r);
+          }
+        }
+      }
+
+      // ---- P^T fragments: k-step s4 covers keys 32 s4 + 8 g + j = tiles (2 s4, 2 s4 + 1)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        bf16x8 t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          t[r] = (__bf16)s[qb][2 * s4][r];
+          t[4 + r] = (__bf16)s[qb][2 * s4 + 1][r];
+        }
+        pf[qb][s4] = t;
+      }
     }
 
     // ---- O^T += V^T P^T ; V^T fragment via two transposing reads of 4 keys x 16 d
@@ -197,25 +209,30 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
         const s16x4 hi = lds_read_tr(Vs + kv_off(r0 + 4, ch) + 8 * (p4 & 1));
         union { struct { s16x4 a, b; } s; bf16x8 v; } u;
         u.s.a = lo; u.s.b = hi;
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pf[s4], o[dt], 0, 0, 0);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+          o[qb][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pf[qb][s4], o[qb][dt], 0, 0, 0);
       }
     }
   }
 
-  // ---- normalise and store: lane holds O[q0 + c][16 dt + 4 g + r]
-  const int qrow = q0 + c;
-  const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-  if (qrow < L) {
-    unsigned short* op = out + ((size_t)b * L + qrow) * d + (size_t)h * DH + 4 * g;
+  // ---- normalise and store: lane holds O[q0 + 16 qb + c][16 dt + 4 g + r]
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-      u32x2 w;
-      w[0] = bd_pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv);
-      w[1] = bd_pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
-      *(u32x2*)(op + 16 * dt) = w;
+  for (int qb = 0; qb < QB; ++qb) {
+    const int qrow = q0 + 16 * qb + c;
+    const float inv = l_run[qb] > 0.f ? 1.0f / l_run[qb] : 0.f;
+    if (qrow < L) {
+      unsigned short* op = out + ((size_t)b * L + qrow) * d + (size_t)h * DH + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        u32x2 w;
+        w[0] = bd_pack_bf16x2(o[qb][dt][0] * inv, o[qb][dt][1] * inv);
+        w[1] = bd_pack_bf16x2(o[qb][dt][2] * inv, o[qb][dt][3] * inv);
+        *(u32x2*)(op + 16 * dt) = w;
+      }
+      if (lse_out != nullptr && g == 0)
+        lse_out[((size_t)b * H + h) * L + qrow] = l_run[qb] > 0.f ? (m_run[qb] + __logf(l_run[qb])) : -INFINITY;
     }
-    if (lse_out != nullptr && g == 0)
-      lse_out[((size_t)b * H + h) * L + qrow] = l_run > 0.f ? (m_run + __logf(l_run)) : -INFINITY;
   }
 }
 
@@ -224,14 +241,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
 // qkv [B*L, 3*H*DH] bf16, keymask [B, L] bytes (non-zero = visible) or null,
 // out [B*L, H*DH] bf16, lse (optional) [B, H, L] fp32 log-sum-exp of the scaled scores.
 template <int DH>
-static void launch_attn_fwd(dim3 grid, hipStream_t s, const void* qkv, const unsigned char* keymask, void* out, float* lse,
+static void launch_attn_fwd(hipStream_t s, const void* qkv, const unsigned char* keymask, void* out, float* lse, int B,
                             int L, int H, float scale, const bd_drop_args& da) {
-  if (da.thr != 0u)
-    hipLaunchKernelGGL((attn_fwd_kernel<DH, true>), grid, dim3(256), 0, s, (const unsigned short*)qkv, keymask,
-                       (unsigned short*)out, lse, L, H, scale, da);
-  else
-    hipLaunchKernelGGL((attn_fwd_kernel<DH, false>), grid, dim3(256), 0, s, (const unsigned short*)qkv, keymask,
-                       (unsigned short*)out, lse, L, H, scale, da);
+  const unsigned short* q = (const unsigned short*)qkv;
+  unsigned short* o = (unsigned short*)out;
+  if (L > 64) {      // two query blocks per wave: 128 queries per workgroup
+    dim3 grid((L + 127) / 128, H, B);
+    if (da.thr != 0u) hipLaunchKernelGGL((attn_fwd_kernel<DH, true, 2>), grid, dim3(256), 0, s, q, keymask, o, lse, L, H, scale, da);
+    else hipLaunchKernelGGL((attn_fwd_kernel<DH, false, 2>), grid, dim3(256), 0, s, q, keymask, o, lse, L, H, scale, da);
+  } else {
+    dim3 grid((L + 63) / 64, H, B);
+    if (da.thr != 0u) hipLaunchKernelGGL((attn_fwd_kernel<DH, true, 1>), grid, dim3(256), 0, s, q, keymask, o, lse, L, H, scale, da);
+    else hipLaunchKernelGGL((attn_fwd_kernel<DH, false, 1>), grid, dim3(256), 0, s, q, keymask, o, lse, L, H, scale, da);
+  }
 }
 
 extern "C" int bd_attention_fwd_drop(const void* qkv, const unsigned char* keymask, void* out, float* lse, int B, int L,
@@ -243,12 +265,11 @@ extern "C" int bd_attention_fwd_drop(const void* qkv, const unsigned char* keyma
   BD_REQUIRE(bd_drop_make(drop, site, &da), "bd_attention_fwd: dropout p=%g outside [0, 1)", (double)drop->p);
   BD_REQUIRE(da.thr == 0u || (long long)B * H * L < (1ll << 32), "bd_attention_fwd: dropout needs B*H*L < 2^32");
   const float scale = 1.0f / sqrtf((float)head_dim);
-  dim3 grid((L + 63) / 64, H, B);
   hipStream_t s = (hipStream_t)stream;
   switch (head_dim) {
-    case 32: launch_attn_fwd<32>(grid, s, qkv, keymask, out, lse, L, H, scale, da); break;
-    case 64: launch_attn_fwd<64>(grid, s, qkv, keymask, out, lse, L, H, scale, da); break;
-    case 128: launch_attn_fwd<128>(grid, s, qkv, keymask, out, lse, L, H, scale, da); break;
+    case 32: launch_attn_fwd<32>(s, qkv, keymask, out, lse, B, L, H, scale, da); break;
+    case 64: launch_attn_fwd<64>(s, qkv, keymask, out, lse, B, L, H, scale, da); break;
+    case 128: launch_attn_fwd<128>(s, qkv, keymask, out, lse, B, L, H, scale, da); break;
     default:
       return bd_fail(BD_ERR_UNSUPPORTED, "bd_attention_fwd: head_dim %d not in {32, 64, 128}", head_dim);
   }
