@@ -77,6 +77,107 @@ __device__ __forceinline__ void drop_factors16(const bd_drop_args& d, int m, int
   }
 }
 
+// Epilogue of one output row segment: v = acc + bias for the 16 consecutive columns nb .. nb + 15
+// of row m; applies the epilogue's activation / dropout / residual and stores.
+template <int EPI, bool DROP>
+__device__ __forceinline__ void epilogue_row(const GemmArgs& p, int m, int nb, float (&v)[16]) {
+  if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_DGELU_BF16 || EPI == EPI_AXPBY_BF16) {
+    if (EPI == EPI_AXPBY_BF16) {
+      const unsigned short* xi = (const unsigned short*)p.aux_in + (size_t)m * p.ldc + nb;
+      const u32x4 lo = *(const u32x4*)(xi), hi = *(const u32x4*)(xi + 8);
+      float x[16];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        x[2 * e] = __uint_as_float(lo[e] << 16);     x[2 * e + 1] = __uint_as_float(lo[e] & 0xffff0000u);
+        x[8 + 2 * e] = __uint_as_float(hi[e] << 16); x[8 + 2 * e + 1] = __uint_as_float(hi[e] & 0xffff0000u);
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float prod = bd_bf16_to_f32(bd_f32_to_bf16(v[j]));
+        v[j] = bd_bf16_to_f32(bd_f32_to_bf16(p.beta * x[j])) + bd_bf16_to_f32(bd_f32_to_bf16(p.alpha * prod));
+      }
+    }
+    if (EPI == EPI_BIAS_GELU_BF16) {
+      if (p.aux_out != nullptr) {
+        unsigned short* uo = (unsigned short*)p.aux_out + (size_t)m * p.ldc + nb;
+        u32x4 lo, hi;
+        lo[0] = bd_pack_bf16x2(v[0], v[1]);   lo[1] = bd_pack_bf16x2(v[2], v[3]);
+        lo[2] = bd_pack_bf16x2(v[4], v[5]);   lo[3] = bd_pack_bf16x2(v[6], v[7]);
+        hi[0] = bd_pack_bf16x2(v[8], v[9]);   hi[1] = bd_pack_bf16x2(v[10], v[11]);
+        hi[2] = bd_pack_bf16x2(v[12], v[13]); hi[3] = bd_pack_bf16x2(v[14], v[15]);
+        *(u32x4*)(uo) = lo;
+        *(u32x4*)(uo + 8) = hi;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = gelu_erf(v[j]);
+    }
+    if (DROP) {
+      float f[16];
+      drop_factors16(p.drop, m, nb, f);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] *= f[j];
+    }
+    if (EPI == EPI_DGELU_BF16) {
+      const unsigned short* ui = (const unsigned short*)p.aux_in + (size_t)m * p.ldc + nb;
+      const u32x4 lo = *(const u32x4*)(ui), hi = *(const u32x4*)(ui + 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[2 * e] *= gelu_grad(__uint_as_float(lo[e] << 16));
+        v[2 * e + 1] *= gelu_grad(__uint_as_float(lo[e] & 0xffff0000u));
+        v[8 + 2 * e] *= gelu_grad(__uint_as_float(hi[e] << 16));
+        v[8 + 2 * e + 1] *= gelu_grad(__uint_as_float(hi[e] & 0xffff0000u));
+      }
+    }
+    unsigned short* o = (unsigned short*)p.out + (size_t)m * p.ldc + nb;
+    u32x4 lo, hi;
+    lo[0] = bd_pack_bf16x2(v[0], v[1]);   lo[1] = bd_pack_bf16x2(v[2], v[3]);
+    lo[2] = bd_pack_bf16x2(v[4], v[5]);   lo[3] = bd_pack_bf16x2(v[6], v[7]);
+    hi[0] = bd_pack_bf16x2(v[8], v[9]);   hi[1] = bd_pack_bf16x2(v[10], v[11]);
+    hi[2] = bd_pack_bf16x2(v[12], v[13]); hi[3] = bd_pack_bf16x2(v[14], v[15]);
+    *(u32x4*)(o) = lo;
+    *(u32x4*)(o + 8) = hi;
+  } else if (EPI == EPI_BIAS_RESID_F32) {
+    float* o = (float*)p.out + (size_t)m * p.ldc + nb;
+    const float* ri = p.aux_in ? (const float*)p.aux_in + (size_t)m * p.ldc + nb : o;
+    if (DROP) {
+      float f[16];
+      drop_factors16(p.drop, m, nb, f);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] *= f[j];
+    }
+#pragma unroll
+    for (int j4 = 0; j4 < 4; ++j4) {
+      f32x4 x = *(const f32x4*)(ri + 4 * j4);
+      x[0] += v[4 * j4 + 0]; x[1] += v[4 * j4 + 1]; x[2] += v[4 * j4 + 2]; x[3] += v[4 * j4 + 3];
+      *(f32x4*)(o + 4 * j4) = x;
+    }
+  } else {  // EPI_F32, ragged N
+    float* o = (float*)p.out + (size_t)m * p.ldc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (nb + j < p.n_real) o[nb + j] = v[j];
+  }
+}
+
+// bias of the 16 consecutive columns nb .. nb + 15 (zeros without a bias)
+template <int EPI>
+__device__ __forceinline__ void load_bias16(const GemmArgs& p, int nb, float (&bv)[16]) {
+#pragma unroll
+  for (int j = 0; j < 16; ++j) bv[j] = 0.f;
+  if (p.bias != nullptr) {
+    if (EPI == EPI_F32) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) bv[j] = (nb + j) < p.n_real ? p.bias[nb + j] : 0.f;
+    } else {
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) {
+        const f32x4 t = *(const f32x4*)(p.bias + nb + 4 * j4);
+        bv[4 * j4 + 0] = t[0]; bv[4 * j4 + 1] = t[1]; bv[4 * j4 + 2] = t[2]; bv[4 * j4 + 3] = t[3];
+      }
+    }
+  }
+}
+
 template <int EPI, bool DROP>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];
@@ -211,20 +312,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
   // ---- epilogue: lane (g, c) holds, for m-tile tm, n = nb + 4 tn + r (16 consecutive)
   const int nb = n0 + wn * 64 + 16 * g;
   float bv[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) bv[j] = 0.f;
-  if (p.bias != nullptr) {
-    if (EPI == EPI_F32) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) bv[j] = (nb + j) < p.n_real ? p.bias[nb + j] : 0.f;
-    } else {
-#pragma unroll
-      for (int j4 = 0; j4 < 4; ++j4) {
-        const f32x4 t = *(const f32x4*)(p.bias + nb + 4 * j4);
-        bv[4 * j4 + 0] = t[0]; bv[4 * j4 + 1] = t[1]; bv[4 * j4 + 2] = t[2]; bv[4 * j4 + 3] = t[3];
-      }
-    }
-  }
+  load_bias16<EPI>(p, nb, bv);
 #pragma unroll
   for (int tm = 0; tm < 4; ++tm) {
     const int m = m0 + wm * 64 + 16 * tm + c;
@@ -234,84 +322,135 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[4 * tn + r] = acc[tn][tm][r] + bv[4 * tn + r];
-    if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_DGELU_BF16 || EPI == EPI_AXPBY_BF16) {
-      if (EPI == EPI_AXPBY_BF16) {
-        const unsigned short* xi = (const unsigned short*)p.aux_in + (size_t)m * p.ldc + nb;
-        const u32x4 lo = *(const u32x4*)(xi), hi = *(const u32x4*)(xi + 8);
-        float x[16];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          x[2 * e] = __uint_as_float(lo[e] << 16);     x[2 * e + 1] = __uint_as_float(lo[e] & 0xffff0000u);
-          x[8 + 2 * e] = __uint_as_float(hi[e] << 16); x[8 + 2 * e + 1] = __uint_as_float(hi[e] & 0xffff0000u);
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const float prod = bd_bf16_to_f32(bd_f32_to_bf16(v[j]));
-          v[j] = bd_bf16_to_f32(bd_f32_to_bf16(p.beta * x[j])) + bd_bf16_to_f32(bd_f32_to_bf16(p.alpha * prod));
-        }
-      }
-      if (EPI == EPI_BIAS_GELU_BF16) {
-        if (p.aux_out != nullptr) {
-          unsigned short* uo = (unsigned short*)p.aux_out + (size_t)m * p.ldc + nb;
-          u32x4 lo, hi;
-          lo[0] = bd_pack_bf16x2(v[0], v[1]);   lo[1] = bd_pack_bf16x2(v[2], v[3]);
-          lo[2] = bd_pack_bf16x2(v[4], v[5]);   lo[3] = bd_pack_bf16x2(v[6], v[7]);
-          hi[0] = bd_pack_bf16x2(v[8], v[9]);   hi[1] = bd_pack_bf16x2(v[10], v[11]);
-          hi[2] = bd_pack_bf16x2(v[12], v[13]); hi[3] = bd_pack_bf16x2(v[14], v[15]);
-          *(u32x4*)(uo) = lo;
-          *(u32x4*)(uo + 8) = hi;
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = gelu_erf(v[j]);
-      }
-      if (DROP) {
-        float f[16];
-        drop_factors16(p.drop, m, nb, f);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] *= f[j];
-      }
-      if (EPI == EPI_DGELU_BF16) {
-        const unsigned short* ui = (const unsigned short*)p.aux_in + (size_t)m * p.ldc + nb;
-        const u32x4 lo = *(const u32x4*)(ui), hi = *(const u32x4*)(ui + 8);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[2 * e] *= gelu_grad(__uint_as_float(lo[e] << 16));
-          v[2 * e + 1] *= gelu_grad(__uint_as_float(lo[e] & 0xffff0000u));
-          v[8 + 2 * e] *= gelu_grad(__uint_as_float(hi[e] << 16));
-          v[8 + 2 * e + 1] *= gelu_grad(__uint_as_float(hi[e] & 0xffff0000u));
-        }
-      }
-      unsigned short* o = (unsigned short*)p.out + (size_t)m * p.ldc + nb;
-      u32x4 lo, hi;
-      lo[0] = bd_pack_bf16x2(v[0], v[1]);   lo[1] = bd_pack_bf16x2(v[2], v[3]);
-      lo[2] = bd_pack_bf16x2(v[4], v[5]);   lo[3] = bd_pack_bf16x2(v[6], v[7]);
-      hi[0] = bd_pack_bf16x2(v[8], v[9]);   hi[1] = bd_pack_bf16x2(v[10], v[11]);
-      hi[2] = bd_pack_bf16x2(v[12], v[13]); hi[3] = bd_pack_bf16x2(v[14], v[15]);
-      *(u32x4*)(o) = lo;
-      *(u32x4*)(o + 8) = hi;
-    } else if (EPI == EPI_BIAS_RESID_F32) {
-      float* o = (float*)p.out + (size_t)m * p.ldc + nb;
-      const float* ri = p.aux_in ? (const float*)p.aux_in + (size_t)m * p.ldc + nb : o;
-      if (DROP) {
-        float f[16];
-        drop_factors16(p.drop, m, nb, f);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] *= f[j];
-      }
-#pragma unroll
-      for (int j4 = 0; j4 < 4; ++j4) {
-        f32x4 x = *(const f32x4*)(ri + 4 * j4);
-        x[0] += v[4 * j4 + 0]; x[1] += v[4 * j4 + 1]; x[2] += v[4 * j4 + 2]; x[3] += v[4 * j4 + 3];
-        *(f32x4*)(o + 4 * j4) = x;
-      }
-    } else {  // EPI_F32, ragged N
-      float* o = (float*)p.out + (size_t)m * p.ldc;
-#pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (nb + j < p.n_real) o[nb + j] = v[j];
-    }
+    epilogue_row<EPI, DROP>(p, m, nb, v);
   }
   }   // persistent tile loop
+}
+
+// -------------------------------------------------------------------------------------------------
+// Large-tile variant for Npad % 256 == 0: 256 x 256 output tile per workgroup, 4 waves (2 x 2) of
+// 128 x 128 each, 32x32x16 MFMAs, fp32 accumulators in 256 registers per lane, one wave per SIMD.
+// The 64 x 64 wave tile above reads 1 KiB of LDS per 2 MFMAs and saturates the LDS pipe together
+// with the MFMA pipe; a 128 x 128 wave tile reads half as much per flop.
+//  * Operands reach LDS by LDS-DMA in FRAGMENT order: a 1-KiB fragment is, lane by lane, the operand
+//    of one MFMA (lane = 32 kh + r holds row r, k = 16 q + 8 kh .. +7), so LDS reads are lane-linear
+//    and conflict-free without a swizzle. The lane's global address does the gather.
+//  * Weight rows are permuted inside a 32-row tile (MFMA row rho <-> column 16 ((rho >> 2) & 1) +
+//    4 (rho >> 3) + (rho & 3)) so that a lane's 16 accumulators of a tile are 16 consecutive n.
+//  * Two 64-KiB stages (BK = 64): the next stage's DMA runs during this stage's 64 MFMAs per wave.
+//    LDS reads are inline asm with their own waits (the compiler would wait for the DMA in flight).
+// -------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) void g256_glb;
+typedef __attribute__((address_space(3))) void g256_lds;
+constexpr int G256_STAGE = 65536, G256_PART = 32768;
+
+template <int EPI, bool DROP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm256_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem256[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int kh = lane >> 5, r = lane & 31;
+  if (EPI == EPI_AXPBY_BF16 || EPI == EPI_BIAS_BF16) {
+    const long long b = blockIdx.y;
+    p.A += b * p.sA;
+    p.W += b * p.sW;
+    p.out = (unsigned short*)p.out + b * p.sOut;
+    if (EPI == EPI_AXPBY_BF16) p.aux_in = (const unsigned short*)p.aux_in + b * p.sOut;
+  }
+  int tile;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q = nwg >> 3, rr = nwg & 7, xcd = orig & 7;
+    tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
+  }
+  const int tiles_n = p.Npad >> 8;
+  const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
+  const int K = p.K, nk = K / 64;
+
+  // DMA: wave w moves the fragments with k16 index q = w of all 16 (part, tile) pairs of a stage
+  const int nperm = 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);
+  const unsigned short* gw = p.W + (size_t)(n0 + nperm) * K + 16 * wave + 8 * kh;
+  const unsigned short* garow[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    int am = m0 + 32 * t + r;
+    am = am < p.M ? am : p.M - 1;
+    garow[t] = p.A + (size_t)am * K + 16 * wave + 8 * kh;
+  }
+  auto issue = [&](int s) {
+    unsigned char* st = smem256 + (s & 1) * G256_STAGE + wave * 1024;
+    const int k0 = s * 64;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+      __builtin_amdgcn_global_load_lds((g256_glb*)(gw + (size_t)(32 * t) * K + k0), (g256_lds*)(st + t * 4096), 16, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+      __builtin_amdgcn_global_load_lds((g256_glb*)(garow[t] + k0), (g256_lds*)(st + G256_PART + t * 4096), 16, 0, 0);
+  };
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      asm volatile("" : "+a"(acc[i][j]));
+    }
+
+  // fragment addresses of this wave inside a stage: W tiles 4 wn + j, A tiles 4 wm + j, k16 index q
+  const unsigned lds0 = (unsigned)(size_t)(g256_lds*)smem256 + lane * 16;
+  const unsigned wbase = lds0 + (4 * wn) * 4096, abase = lds0 + G256_PART + (4 * wm) * 4096;
+
+  issue(0);
+  for (int s = 0; s < nk; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (s + 1 < nk) issue(s + 1);
+    const unsigned so = (s & 1) * G256_STAGE;
+    bf16x8 fw[2][4], fa[2][4];
+    auto reads = [&](int q, int b) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fw[b][j]) : "v"(wbase + so + q * 1024), "i"(j * 4096));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[b][j]) : "v"(abase + so + q * 1024), "i"(j * 4096));
+      }
+    };
+    reads(0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int b = q & 1;
+      // every register written by the reads of step q passes through this wait before its first use
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(fw[b][0]), "+v"(fw[b][1]), "+v"(fw[b][2]), "+v"(fw[b][3]), "+v"(fa[b][0]), "+v"(fa[b][1]),
+                     "+v"(fa[b][2]), "+v"(fa[b][3]));
+      if (q + 1 < 4) reads(q + 1, b ^ 1);
+      __builtin_amdgcn_sched_barrier(0);      // the next step's reads go out before this step's MFMAs
+#pragma unroll
+      for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+        for (int jm = 0; jm < 4; ++jm)
+          acc[jn][jm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[b][jn], fa[b][jm], acc[jn][jm], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- epilogue: tile (jn, jm): lane holds row m = m0 + 128 wm + 32 jm + r, columns nb .. nb + 15
+#pragma unroll
+  for (int jn = 0; jn < 4; ++jn) {
+    const int nb = n0 + 128 * wn + 32 * jn + 16 * kh;
+    float bv[16];
+    load_bias16<EPI>(p, nb, bv);
+#pragma unroll
+    for (int jm = 0; jm < 4; ++jm) {
+      const int m = m0 + 128 * wm + 32 * jm + r;
+      if (m >= p.M) continue;
+      float v[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = acc[jn][jm][e] + bv[e];
+      epilogue_row<EPI, DROP>(p, m, nb, v);
+    }
+  }
 }
 
 // Persistent grid: two workgroups per CU (what the kernel's registers and 64 KB of LDS allow), a
@@ -329,10 +468,24 @@ int persistent_grid(int n_tiles) {
   return n_tiles <= slots ? n_tiles : slots;
 }
 
+// the large-tile kernel pays when the problem fills the chip with 256 x 256 tiles
+bool use_gemm256(const GemmArgs& a) {
+  static int mode = getenv("BD_GEMM256") ? atoi(getenv("BD_GEMM256")) : 1;
+  if (!mode || a.Npad % 256 != 0 || a.n_real != a.Npad) return false;
+  if (a.K < 768) return false;        // few k-steps: the 128 x 128 kernel with two workgroups per CU hides its epilogue better
+  return (((long long)a.M + 255) / 256) * (a.Npad / 256) >= 128;
+}
+
 template <int EPI, bool DROP = false>
 int launch(const GemmArgs& a, hipStream_t s) {
   void* tok = bd_prof_on() ? bd_prof_begin(s) : nullptr;
-  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, DROP>), dim3(persistent_grid(a.n_tiles)), dim3(256), 0, s, a);
+  if (use_gemm256(a)) {
+    const long long nt = (((long long)a.M + 255) / 256) * (a.Npad / 256);
+    hipFuncSetAttribute((const void*)gemm256_kernel<EPI, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G256_STAGE);
+    hipLaunchKernelGGL((gemm256_kernel<EPI, DROP>), dim3((unsigned)nt), dim3(256), 2 * G256_STAGE, s, a);
+  } else {
+    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, DROP>), dim3(persistent_grid(a.n_tiles)), dim3(256), 0, s, a);
+  }
   if (tok) bd_prof_end(tok, s, 2.0 * (double)a.M * (double)a.n_real * (double)a.K);
   return bd_check_launch("bd_gemm_bf16");
 }

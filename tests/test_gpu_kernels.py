@@ -400,3 +400,63 @@ def test_attn_block_unsupported_shapes_are_refused(gpu_device):
     a = torch.zeros(1024, device=gpu_device)
     assert lib.bd_attn_block_fused(_lib.ptr(a), _lib.ptr(a), _lib.ptr(a), _lib.ptr(a), _lib.ptr(a), _lib.ptr(a), None, 1, 200, 384, 3,
                                    1e-5, _s()) < 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(16411, 512, 768), (32768, 1536, 1024), (8200, 1024, 1024), (33000, 256, 832)])
+def test_large_tile_gemm_all_epilogues(gpu_device, M, N, K):
+    """Shapes that take the 256 x 256-tile kernel (N % 256 == 0, >= 128 tiles): every epilogue against fp32 torch,
+    ragged last row tile included; exact for small-integer operands."""
+    import ctypes as C
+    from oracle import sampler_ref as ora
+    dev = gpu_device
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(dev).bfloat16()
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev).bfloat16()
+    bias = torch.randn(N, generator=g).to(dev)
+    s = _lib.stream_handle()
+    lib = _lib.lib()
+    pre = A.float() @ W.float().t() + bias
+
+    def run(epi, out, aux_in=None, aux_out=None, drop=None, b=bias):
+        d = None if drop is None else C.byref(drop)
+        _lib.check(lib.bd_gemm_bf16_drop(_lib.ptr(A), _lib.ptr(W), _lib.ptr(b), _lib.ptr(out), _lib.ptr(aux_in),
+                                         _lib.ptr(aux_out), M, N, N, K, N, epi, d, 3, s), "gemm")
+
+    def rel(a, b):
+        return float((a.float() - b.float()).norm() / b.float().norm())
+
+    o0 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+    run(0, o0)
+    assert torch.isfinite(o0.float()).all() and rel(o0, pre) < 4e-3
+    u = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    o1 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    run(1, o1, aux_out=u)
+    assert rel(u, pre) < 4e-3 and rel(o1, torch.nn.functional.gelu(pre)) < 6e-3
+    resid = torch.randn(M, N, generator=g).to(dev)
+    o2 = torch.empty(M, N, device=dev)
+    run(2, o2, aux_in=resid)
+    assert rel(o2 - resid, pre) < 4e-3
+    o2b = resid.clone()
+    run(2, o2b)                       # in place on the residual stream
+    assert torch.equal(o2b, o2)
+    o3 = torch.empty(M, N, device=dev)
+    run(3, o3)
+    assert rel(o3, pre) < 1e-3 or rel(o3, pre) < 4e-3
+    ur = u.float().requires_grad_(True)
+    torch.nn.functional.gelu(ur).sum().backward()
+    o4 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    run(4, o4, aux_in=u, b=None)
+    assert rel(o4, (A.float() @ W.float().t()) * ur.grad) < 1e-2
+    drop = _lib.Dropout(0.1, 5, 77)
+    f = torch.from_numpy(ora.dropout_mask(77, 5, 3, 0.1, M, N)).to(dev)
+    o1d = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    run(1, o1d, drop=drop)
+    assert bool((o1d[f == 0] == 0).all()) and rel(o1d, torch.nn.functional.gelu(pre) * f) < 6e-3
+    # exact arithmetic on small integers (any mis-addressed fragment shows up as a wrong integer)
+    Ai = torch.randint(-3, 4, (M, K), generator=g).float()
+    Wi = torch.randint(-3, 4, (N, K), generator=g).float()
+    A, W = Ai.to(dev).bfloat16(), Wi.to(dev).bfloat16()
+    oi = torch.empty(M, N, device=dev)
+    run(3, oi, b=None)
+    assert torch.equal(oi.cpu(), Ai @ Wi.t())
