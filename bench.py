@@ -120,7 +120,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--seq-len", type=int, default=128)
     ap.add_argument("--diffusion-steps", type=int, default=100)
-    ap.add_argument("--cpu-seqs", type=int, default=96, help="sequences in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-seqs", type=int, default=64, help="sequences in the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-constraints", action="store_true")
     ap.add_argument("--train-steps", type=int, default=20, help="timed training steps (0 = skip the training leg)")
     args = ap.parse_args()
