@@ -155,3 +155,21 @@ def test_collate_kernel_flags_bad_rows_and_large_batches(gpu_device):
     flag = int(err.item())
     assert flag & 1 and (flag & 2) == (2 if max(lens[0], lens[2]) > 4 else 0)
     assert out_m[1].sum().item() == 0 and (out_i[1] == 3).all()
+
+
+def test_bucket_sampler_ranks_partition_the_epoch():
+    """Every rank gets the same number of samples, together they cover the data set (the wrap-around
+    padding repeats at most world - 1 samples), and a new epoch reshuffles."""
+    n, world = 1003, 4
+    lengths = RI.sampler_lengths(n).tolist()
+    per_rank = []
+    for rank in range(world):
+        smp = LengthBucketBatchSampler(lengths, 16, seed=5, bucket_size_multiplier=3, num_replicas=world, rank=rank)
+        smp.set_epoch(2)
+        per_rank.append([i for b in smp for i in b])
+    assert len({len(x) for x in per_rank}) == 1 and len(per_rank[0]) == -(-n // world)
+    allidx = [i for x in per_rank for i in x]
+    assert set(allidx) == set(range(n)) and len(allidx) - n == world * len(per_rank[0]) - n < world
+    smp = LengthBucketBatchSampler(lengths, 16, seed=5, bucket_size_multiplier=3, num_replicas=world, rank=0)
+    smp.set_epoch(3)
+    assert [i for b in smp for i in b] != per_rank[0]
