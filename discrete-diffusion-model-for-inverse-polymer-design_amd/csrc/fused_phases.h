@@ -14,10 +14,10 @@ typedef __attribute__((address_space(3))) bf16x8* lds_frag_w;
 typedef const __attribute__((address_space(3))) f32x4* lds_f4;
 typedef const __attribute__((address_space(3))) float* lds_f1;
 
-struct Gelu2 { float x0, x1, s0, s1, p0, p1; };
+struct Gelu4 { float x[4], s[4], p[4]; };
 
 // bytes of LDS the phases need
-__host__ __device__ constexpr size_t ffn_phase_lds(int NT, int F) { return 6 * (size_t)NT * 1024 + ((size_t)F + 32) * 4; }
+__host__ __device__ constexpr size_t ffn_phase_lds(int NT, int F) { return 6 * (size_t)NT * 1024 + ((size_t)F + 64) * 4; }
 __host__ __device__ constexpr size_t attn_phase_lds(int NT, int DH) {
   return 3 * (size_t)NT * 1024 + 2 * (size_t)128 * DH * 2 + (size_t)NT * 16 * 4 + 128 * 4;
 }
@@ -60,7 +60,7 @@ __device__ __forceinline__ void stagger_start(int stagger_blocks, int stagger_un
 
 // ---------------------------------------------------------------------------------------------
 // Feed-forward phase: acc (in) = the wave's 32 residual rows, acc (out) = rows + W2 GELU(W1 LN(rows)
-// + b1) + b2. smem: 6 units + (F + 32) floats. All four waves of the workgroup call it together;
+// + b1) + b2. smem: 6 units + (F + 64) floats. All four waves of the workgroup call it together;
 // nobody may still be using smem when they enter.
 struct FfnPhase {
   const unsigned char* wpack;   // packed weight stream (bd_ffn_pack_weights)
@@ -79,11 +79,13 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
   constexpr int NT32 = NT / 2;                // 32-feature tiles of the residual row
   constexpr int UNIT = NT * 1024;             // unit 2 j = W1 of chunk j, unit 2 j + 1 = W2 of chunk j
   constexpr int RING = 6;
-  constexpr int PER_UNIT = NT / 4;
-  constexpr int NF = 2 * NT;                  // fragments (= MFMAs) per chunk
-  constexpr int FB = 8;                       // fragment read batch
-  static_assert(NT % FB == 0, "fragment batches must tile both GEMMs");
-  float* const sb1 = (float*)(smem + RING * UNIT);     // F + 32 floats
+  constexpr int PER_UNIT = NT / 4;            // 1-KiB pieces of a unit that one wave moves
+  constexpr int NF = 2 * NT;                  // fragments (= MFMAs) per chunk iteration
+  constexpr int LOOK = 8;                     // fragment reads in flight ahead of their MFMA
+  constexpr int SYNC = NF - LOOK;             // step of the iteration's barrier
+  constexpr int DMA_EVERY = 4;                // one piece every fourth step: 2 PER_UNIT pieces per iteration
+  static_assert(NT % 8 == 0 && NF / DMA_EVERY == 2 * PER_UNIT && PER_UNIT >= 2, "unsupported width");
+  float* const sb1 = (float*)(smem + RING * UNIT);     // F + 64 floats
   typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
   typedef const __attribute__((address_space(3))) f32x4* lds_f4;
 
@@ -93,19 +95,20 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
   const int nch = p.F >> 5;
   const int nunits = 2 * nch;
 
+  // this wave's k-th 1-KiB piece of unit u -> ring slot u % RING
+  auto issue_piece = [&](int u, int k) {
+    const int f = wave + 4 * k;
+    __builtin_amdgcn_global_load_lds((glb_void*)(p.wpack + (size_t)u * UNIT + lane * 16 + f * 1024),
+                                     (lds_void*)(smem + (u % RING) * UNIT + f * 1024), 16, 0, 0);
+  };
   auto issue_unit = [&](int u) {
-    const unsigned char* src = p.wpack + (size_t)u * UNIT + lane * 16;
-    unsigned char* dst = smem + (u % RING) * UNIT;
 #pragma unroll
-    for (int i = 0; i < PER_UNIT; ++i) {
-      const int f = wave + 4 * i;
-      __builtin_amdgcn_global_load_lds((glb_void*)(src + f * 1024), (lds_void*)(dst + f * 1024), 16, 0, 0);
-    }
+    for (int k = 0; k < PER_UNIT; ++k) issue_piece(u, k);
   };
 
 #pragma unroll
   for (int u = 0; u < 5; ++u) issue_unit(u);            // F >= 96: the first five units exist
-  for (int i = tid; i < p.F + 32; i += 256) sb1[i] = i < p.F ? p.b1[i] : 0.f;
+  for (int i = tid; i < p.F + 64; i += 256) sb1[i] = i < p.F ? p.b1[i] : 0.f;
 
   // ---- LayerNorm -> bf16 B operands (gamma / beta are folded into W1 and b1)
   bf16x8 xln[NT];
@@ -138,110 +141,43 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
 
   f32x16 hn_cur, hn_next;      // GEMM1 results of chunk j and j + 1 (rows = hidden units of the chunk)
   bf16x8 hb[2], hb0_next;      // GELU(hn_cur) as the two B operands of GEMM2; first half of the next
-  Gelu2 gs;
+  Gelu4 gs = {};
 
-  // GELU part g (0..47): pair g / 6 = registers 2 pair, 2 pair + 1 of the source tile, in six parts
+  // GELU part g (0..47) of a 16-value tile: quad g / 12 = registers 4 quad .. 4 quad + 3 of the source tile, in twelve
+  // parts of ONE operation on each of the four values. Four independent chains: a vector operation that needs the
+  // result of the one issued two slots earlier waits for it (two interleaved chains cost 8 cycles per dependent
+  // operation beside MFMAs, four chains cost the 4 cycles of their issue).
   auto gelu_part = [&](int g, const f32x16& src, bf16x8& dst) {
-    const int pair = g / 6, part = g % 6;
+    const int quad = g / 12, part = g % 12;
+    constexpr float C[8] = {-1.903182666e-09f, 1.410586241e-07f, -4.565313249e-06f, 8.634553992e-05f,
+                            -1.085383136e-03f, 9.789848745e-03f, -6.636063135e-02f, 3.989269649e-01f};
     if (part == 0) {
-      gs.x0 = src[2 * pair]; gs.x1 = src[2 * pair + 1];
-      gs.s0 = fminf(gs.x0 * gs.x0, 16.0f); gs.s1 = fminf(gs.x1 * gs.x1, 16.0f);
-      asm volatile("" : "+v"(gs.s0), "+v"(gs.s1));
+#pragma unroll
+      for (int v = 0; v < 4; ++v) { gs.x[v] = src[4 * quad + v]; gs.s[v] = gs.x[v] * gs.x[v]; }
     } else if (part == 1) {
-      gs.p0 = gs.s0 * -1.903182666e-09f + 1.410586241e-07f; gs.p1 = gs.s1 * -1.903182666e-09f + 1.410586241e-07f;
-      gs.p0 = gs.p0 * gs.s0 + -4.565313249e-06f;            gs.p1 = gs.p1 * gs.s1 + -4.565313249e-06f;
-      asm volatile("" : "+v"(gs.p0), "+v"(gs.p1));
+#pragma unroll
+      for (int v = 0; v < 4; ++v) asm("v_min_f32 %0, 0x41800000, %1" : "=v"(gs.s[v]) : "v"(gs.s[v]));   // min(s, 16); fminf() adds a canonicalising max here
     } else if (part == 2) {
-      gs.p0 = gs.p0 * gs.s0 + 8.634553992e-05f;  gs.p1 = gs.p1 * gs.s1 + 8.634553992e-05f;
-      gs.p0 = gs.p0 * gs.s0 + -1.085383136e-03f; gs.p1 = gs.p1 * gs.s1 + -1.085383136e-03f;
-      asm volatile("" : "+v"(gs.p0), "+v"(gs.p1));
-    } else if (part == 3) {
-      gs.p0 = gs.p0 * gs.s0 + 9.789848745e-03f;  gs.p1 = gs.p1 * gs.s1 + 9.789848745e-03f;
-      gs.p0 = gs.p0 * gs.s0 + -6.636063135e-02f; gs.p1 = gs.p1 * gs.s1 + -6.636063135e-02f;
-      asm volatile("" : "+v"(gs.p0), "+v"(gs.p1));
-    } else if (part == 4) {
-      gs.p0 = gs.p0 * gs.s0 + 3.989269649e-01f;  gs.p1 = gs.p1 * gs.s1 + 3.989269649e-01f;
-      gs.p0 = __builtin_amdgcn_fmed3f(gs.x0 * gs.p0 + 0.5f, 0.0f, 1.0f);
-      gs.p1 = __builtin_amdgcn_fmed3f(gs.x1 * gs.p1 + 0.5f, 0.0f, 1.0f);
-      asm volatile("" : "+v"(gs.p0), "+v"(gs.p1));
+#pragma unroll
+      for (int v = 0; v < 4; ++v) gs.p[v] = gs.s[v] * C[0] + C[1];
+    } else if (part <= 8) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) gs.p[v] = gs.p[v] * gs.s[v] + C[part - 1];
+    } else if (part == 9) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) gs.p[v] = __builtin_amdgcn_fmed3f(gs.x[v] * gs.p[v] + 0.5f, 0.0f, 1.0f);
+    } else if (part == 10) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) gs.p[v] = gs.x[v] * gs.p[v];
     } else {
-      const int j0 = 4 * ((pair >> 1) & 1) + 2 * (pair & 1);
-      dst[j0] = (__bf16)(gs.x0 * gs.p0);
-      dst[j0 + 1] = (__bf16)(gs.x1 * gs.p1);
+      // registers 4 quad + v of a 32x32 tile are rows 8 quad + 4 h + v: operand elements 4 (quad % 2) + v of k-block quad / 2
+      const int j0 = 4 * (quad & 1);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) dst[j0 + v] = (__bf16)gs.p[v];
       asm volatile("" : "+v"(dst));
     }
-  };
-
-  // One chunk iteration: GEMM1 of chunk j1 into hn_next, then (unless first) GEMM2 of chunk j1 - 1
-  // from hb. Fragment i < NT is W1 k-block i, fragment NT + 2 T + kk is W2 tile T, k-block kk.
-  // A wave alone on its SIMD must never drain its LDS queue: the fragment reads run LOOK ahead of
-  // their MFMAs and every MFMA waits with an exact count. The compiler only places
-  // wait-for-everything on LDS reads here, so the steady-state path issues its reads and waits as
-  // inline asm (ASM_READS); the one-off first step keeps compiler-managed loads.
-  constexpr int LOOK = 8;
-  auto chunk_step = [&](int j1, auto first_tag) {
-    constexpr bool first = decltype(first_tag)::value;
-    constexpr bool ASM_READS = !first;
-    unsigned W1b = lds0 + ((2 * j1) % RING) * UNIT;
-    unsigned W2b = lds0 + ((2 * j1 + RING - 1) % RING) * UNIT;
-    unsigned bb1 = ldsb + 128 * j1;
-    asm volatile("" : "+v"(W1b), "+v"(W2b), "+v"(bb1));
-    constexpr int nf = first ? NT : NF;
-    bf16x8 wf[NF];
-    auto read_frag = [&](int i) {
-      if (ASM_READS) {
-        if (i < NT) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[i]) : "v"(W1b), "i"(i * 1024));
-        else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[i]) : "v"(W2b), "i"((i - NT) * 1024));
-      } else {
-        wf[i] = *(lds_frag)(size_t)(i < NT ? W1b + i * 1024 : W2b + (i - NT) * 1024);
-      }
-    };
-    // bias first (oldest in the queue), then the first LOOK fragments
-    f32x4 bq[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (ASM_READS) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[q]) : "v"(bb1), "i"(32 * q));
-      else bq[q] = *(lds_f4)(size_t)(bb1 + 32 * q);
-    }
-#pragma unroll
-    for (int i = 0; i < LOOK; ++i) read_frag(i);
-    if (ASM_READS) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]) : "i"(LOOK));
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      hn_next[4 * q + 0] = bq[q][0]; hn_next[4 * q + 1] = bq[q][1]; hn_next[4 * q + 2] = bq[q][2]; hn_next[4 * q + 3] = bq[q][3];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < NF; ++i) {
-      if (i < nf) {
-        if (i + LOOK < nf) read_frag(i + LOOK);
-        // reads younger than fragment i that may stay in flight
-        if (ASM_READS) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(wf[i]) : "i"(i + LOOK < nf ? LOOK : nf - 1 - i));
-        if (i < NT) {
-          hn_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xln[i], hn_next, 0, 0, 0);
-        } else {
-          const int T = (i - NT) >> 1, kk = (i - NT) & 1;
-          acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], hb[kk], acc[T], 0, 0, 0);
-        }
-      }
-      {
-        if (i < NT) {
-          // second half of GELU(hn_cur) -> hb[1], beside GEMM1 (skipped before the first chunk)
-          if (!first) {
-#pragma unroll
-            for (int g = 24 + i * 24 / NT; g < 24 + (i + 1) * 24 / NT; ++g) gelu_part(g, hn_cur, hb[1]);
-          }
-        } else {
-          // first half of GELU(hn_next) -> hb0_next, beside GEMM2 (or alone before the first chunk)
-#pragma unroll
-          for (int g = (i - NT) * 24 / NT; g < (i - NT + 1) * 24 / NT; ++g) gelu_part(g, hn_next, hb0_next);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);     // nothing moves between fragment steps
-    }
-    hn_cur = hn_next;
-    hb[0] = hb0_next;
-    asm volatile("" : "+v"(hb[0]), "+v"(hb[1]));
+    for (int v = 0; v < 4; ++v) asm volatile("" : "+v"(gs.s[v]), "+v"(gs.p[v]));
   };
 
   // units 0, 1, 2 landed (3 and 4 may still be in flight), bias table written
@@ -249,24 +185,146 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  hb[1] = xln[0];                    // defined value; overwritten before its first real use
-  chunk_step(0, std::true_type{});
-
-  for (int j = 0; j < nch; ++j) {
-    // units 2 j + 5 and 2 j + 6 go where units 2 j - 1 and 2 j were read during iteration j - 1
-    const int u5 = 2 * j + 5;
-    if (u5 < nunits) issue_unit(u5);
-    if (u5 + 1 < nunits) issue_unit(u5 + 1);
-    // GEMM1 of chunk j + 1 (past the end: a stale unit and zero biases, result unused), GEMM2 of chunk j
-    chunk_step(j + 1, std::false_type{});
-    // units 2 j + 3 and 2 j + 4 (issued one iteration ago) must have landed for every wave before
-    // the next iteration reads them; what this iteration issued stays in flight
-    if (u5 + 1 < nunits) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_UNIT) : "memory");
-    else if (u5 < nunits) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_UNIT) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ---- before the loop: GEMM1 of chunk 0 (unit 0) and the first half of its GELU; compiler-managed reads
+  {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b = *(lds_f4)(size_t)(ldsb + 32 * q);
+      hn_next[4 * q + 0] = b[0]; hn_next[4 * q + 1] = b[1]; hn_next[4 * q + 2] = b[2]; hn_next[4 * q + 3] = b[3];
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) hn_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(lds_frag)(size_t)(lds0 + i * 1024), xln[i], hn_next, 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 24; ++g) gelu_part(g, hn_next, hb0_next);
+    hn_cur = hn_next;
+    hb[0] = hb0_next;
+    hb[1] = xln[0];                  // defined value; overwritten before its first real use
+    // every wave is done with unit 0: unit 6 takes its slot (the loop issues odd units from 5, even units from 8)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (6 < nunits) issue_unit(6);
   }
+
+  // ---- The loop. Iteration j = GEMM1 of chunk j + 1 (unit 2 j + 2, steps 0 .. NT - 1; past the last chunk a stale
+  // unit and zero biases, result unused) and GEMM2 of chunk j (unit 2 j + 1, steps NT .. NF - 1), with the GELU of
+  // chunk j's second half and of chunk j + 1's first half spread over the steps.
+  // The fragment reads are ONE continuous stream LOOK steps ahead of the MFMAs, across iterations: the last LOOK
+  // steps of an iteration already read the next iteration's biases and first fragments, so the LDS pipeline never
+  // drains. One barrier per iteration, at step SYNC, before the first read of the next iteration's units. When every
+  // wave has reached it,
+  //  (a) units 2 j + 3 and 2 j + 4 have landed (each wave waits for its own pieces before the barrier; only the
+  //      pieces of unit 2 j + 6, issued last, may still be in flight), so the next iteration may read them, and
+  //  (b) nobody reads unit 2 j - 1 (finished in iteration j - 1) or unit 2 j + 2 (finished at step NT - 1) any
+  //      more: their slots take units 2 j + 5 (pieces issued from here to step NT - LOOK of the next iteration;
+  //      it must land before the next barrier) and 2 j + 8 (issued in the steps after those).
+  // Step order: wait for this step's fragment, issue the read LOOK ahead, the step's GELU share, the MFMA: on one
+  // wave per SIMD that order hides about four vector operations per step; read - wait - MFMA - vector exposes them.
+  // One piece inside the loop costs three instructions: the lane's offset into a unit (lane, wave and piece number)
+  // sits in a register per piece number, the unit's bases are scalars, M0 = LDS base + piece offset.
+  unsigned voff[PER_UNIT];
+#pragma unroll
+  for (int k = 0; k < PER_UNIT; ++k) {
+    voff[k] = (unsigned)(lane * 16 + (wave + 4 * k) * 1024);
+    asm volatile("" : "+v"(voff[k]));
+  }
+  const unsigned ldsw = (unsigned)(size_t)(lds_void*)smem + wave * 1024;
+  auto dma_piece = [&](const unsigned char* unit_src, unsigned unit_lds, int k) {
+    asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"
+                 ::"s"(unit_lds), "i"(k * 4096), "v"(voff[k]), "s"(unit_src)
+                 : "memory", "m0", "scc");
+  };
+  bf16x8 wf[NF];
+  f32x4 bq[4];
+  // start the stream for iteration 0: biases of chunk 1, fragments 0 .. LOOK - 1 of unit 2
+  {
+    unsigned W1b = lds0 + 2 * UNIT, bb1 = ldsb + 128;
+    asm volatile("" : "+v"(W1b), "+v"(bb1));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[q]) : "v"(bb1), "i"(32 * q));
+#pragma unroll
+    for (int i = 0; i < LOOK; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[i]) : "v"(W1b), "i"(i * 1024));
+  }
+
+#pragma nounroll
+  for (int j = 0; j < nch; ++j) {
+    unsigned W1b = lds0 + ((2 * j + 2) % RING) * UNIT;        // this iteration's GEMM1 unit
+    unsigned W2b = lds0 + ((2 * j + 1) % RING) * UNIT;        // this iteration's GEMM2 unit
+    unsigned W1n = lds0 + ((2 * j + 4) % RING) * UNIT;        // the next iteration's GEMM1 unit
+    unsigned bbn = ldsb + 128 * (j + 2);                      // the next iteration's biases (zeros past the end)
+    asm volatile("" : "+v"(W1b), "+v"(W2b), "+v"(W1n), "+v"(bbn));
+    // global and LDS bases of the three units this iteration moves pieces of (scalar, once per iteration)
+    const unsigned char* const src_odd = p.wpack + (size_t)(2 * j + 3) * UNIT;
+    const unsigned char* const src_even = p.wpack + (size_t)(2 * j + 6) * UNIT;
+    const unsigned char* const src_next = p.wpack + (size_t)(2 * j + 5) * UNIT;
+    const unsigned lds_odd = ldsw + ((2 * j + 3) % RING) * UNIT;
+    const unsigned lds_even = ldsw + ((2 * j + 6) % RING) * UNIT;
+    const unsigned lds_next = ldsw + ((2 * j + 5) % RING) * UNIT;
+    const bool odd_rest = j >= 1 && 2 * j + 3 < nunits;       // pieces 2.. of unit 2 j + 3 (0 and 1 went out last iteration)
+    const bool even_all = j >= 1 && 2 * j + 6 < nunits;       // unit 2 j + 6 (unit 6 went out before the loop)
+    const bool odd_next = 2 * j + 5 < nunits;                 // pieces 0 and 1 of unit 2 j + 5
+    // biases are the oldest reads in flight; the LOOK fragments behind them may stay
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]) : "i"(LOOK));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      hn_next[4 * q + 0] = bq[q][0]; hn_next[4 * q + 1] = bq[q][1]; hn_next[4 * q + 2] = bq[q][2]; hn_next[4 * q + 3] = bq[q][3];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      if (i == SYNC) {
+        // own pieces of units 2 j + 3 and 2 j + 4 landed; unit 2 j + 6's (or unit 6's, before the loop) may fly
+        if (2 * j + 6 < nunits) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_UNIT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      if (i % DMA_EVERY == 0) {
+        const int slot = i / DMA_EVERY;                       // 0 .. 2 PER_UNIT - 1
+        if (i >= SYNC) {
+          if (odd_next) dma_piece(src_next, lds_next, slot - SYNC / DMA_EVERY);
+        } else if (slot < PER_UNIT - 2) {
+          if (odd_rest) dma_piece(src_odd, lds_odd, slot + 2);
+        } else {
+          if (even_all) dma_piece(src_even, lds_even, slot - (PER_UNIT - 2));
+        }
+      }
+      // wait for fragment i: younger reads in flight are the LOOK - 1 behind it, plus, in the tail, the four bias reads
+      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(wf[i]) : "i"(i > SYNC ? LOOK + 3 : LOOK - 1));
+      if (i == SYNC) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[q]) : "v"(bbn), "i"(32 * q));
+      }
+      {
+        // fragment i + LOOK of the stream: GEMM1 unit, GEMM2 unit, then the next iteration's GEMM1 unit
+        const unsigned base = i >= SYNC ? W1n : (i + LOOK < NT ? W1b : W2b);
+        asm volatile("ds_read_b128 %0, %1 offset:%2"
+                     : "=v"(wf[i + LOOK < NF ? i + LOOK : i + LOOK - NF])
+                     : "v"(base), "i"((i + LOOK < NT ? i + LOOK : i + LOOK < NF ? i + LOOK - NT : i + LOOK - NF) * 1024));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (i < NT) {
+        // second half of GELU(hn_cur) -> hb[1], beside GEMM1
+#pragma unroll
+        for (int g = 24 + i * 24 / NT; g < 24 + (i + 1) * 24 / NT; ++g) gelu_part(g, hn_cur, hb[1]);
+      } else {
+        // first half of GELU(hn_next) -> hb0_next, beside GEMM2
+#pragma unroll
+        for (int g = (i - NT) * 24 / NT; g < (i - NT + 1) * 24 / NT; ++g) gelu_part(g, hn_next, hb0_next);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (i < NT) {
+        hn_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xln[i], hn_next, 0, 0, 0);
+      } else {
+        const int T = (i - NT) >> 1, kk = (i - NT) & 1;
+        acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], hb[kk], acc[T], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);     // nothing moves between fragment steps
+    }
+    hn_cur = hn_next;
+    hb[0] = hb0_next;
+    asm volatile("" : "+v"(hb[0]), "+v"(hb[1]));
+  }
+  // the reads issued for the iteration after the last one
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
   // + b2
 #pragma unroll
@@ -318,14 +376,23 @@ __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* sm
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5;
-  auto issue_unit = [&](int u) {
-    const unsigned char* src = p.wpack + (size_t)u * UNIT + lane * 16;
-    unsigned char* dst = smem + (u % RING) * UNIT;
+  // A unit moves as PER_UNIT 1-KiB pieces per wave, three instructions each: the lane's offset into a unit (lane, wave
+  // and piece number) sits in a register per piece number, the unit's global and LDS bases are scalars.
+  unsigned voff[PER_UNIT];
 #pragma unroll
-    for (int i = 0; i < PER_UNIT; ++i) {
-      const int f = wave + 4 * i;
-      __builtin_amdgcn_global_load_lds((glb_void*)(src + f * 1024), (lds_void*)(dst + f * 1024), 16, 0, 0);
-    }
+  for (int k = 0; k < PER_UNIT; ++k) {
+    voff[k] = (unsigned)(lane * 16 + (wave + 4 * k) * 1024);
+    asm volatile("" : "+v"(voff[k]));
+  }
+  const unsigned ldsw = (unsigned)(size_t)(lds_void*)smem + wave * 1024;
+  auto issue_unit = [&](int u) {
+    const unsigned char* const unit_src = p.wpack + (size_t)u * UNIT;
+    const unsigned unit_lds = ldsw + (u % RING) * UNIT;
+#pragma unroll
+    for (int k = 0; k < PER_UNIT; ++k)
+      asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"
+                   ::"s"(unit_lds), "i"(k * 4096), "v"(voff[k]), "s"(unit_src)
+                   : "memory", "m0", "scc");
   };
 
   // ---- LayerNorm of the wave's 32 rows -> bf16 operands xln[kb] (row / column = token c,

@@ -28,17 +28,34 @@ constexpr int MAXR = BD_SAMPLE_MAX_RING;
 constexpr int PF_MASK0 = 1, PF_FIXED = 2, PF_DYN_BOND = 4, PF_DYN_CLOSE = 8, PF_CLOSE = 16, PF_OPEN = 32,
               PF_BOND = 64, PF_BOOST = 128;
 
+// Working set of one sequence in LDS, carved from dynamic shared memory with the sizes of THIS launch
+// (a fixed worst-case layout of 20 KB per wave would cap a CU at 8 sequences; the small model needs 4 KB).
 struct Smem {
-  int ids[MAXL];
-  unsigned int key[MAXL];
-  float col[MAXL];
-  short sel[MAXL];
-  unsigned char pf[MAXL];
-  float row[MAXV];
-  float h[MAXD];
-  int ringcnt[MAXR];
-  unsigned char ringforbid[MAXR];
+  int* ids;                  // [L]
+  unsigned int* key;         // [L]
+  float* col;                // [L]
+  float* row;                // [V]
+  float* h;                  // [d]
+  int* ringcnt;              // [R]
+  short* sel;                // [L]
+  unsigned char* pf;         // [L]
+  unsigned char* ringforbid; // [R]
 };
+__host__ __device__ inline size_t smem_align4(size_t x) { return (x + 3) & ~(size_t)3; }
+__host__ __device__ inline size_t smem_bytes(int L, int V, int d, int R) {
+  return 4 * ((size_t)3 * L + V + d + R) + smem_align4(2 * (size_t)L) + smem_align4((size_t)L) + smem_align4((size_t)R) + 16;
+}
+__device__ __forceinline__ void smem_carve(Smem& s, unsigned char* raw, int L, int V, int d, int R) {
+  s.ids = (int*)raw;                  raw += 4 * (size_t)L;
+  s.key = (unsigned int*)raw;         raw += 4 * (size_t)L;
+  s.col = (float*)raw;                raw += 4 * (size_t)L;
+  s.row = (float*)raw;                raw += 4 * (size_t)V;
+  s.h = (float*)raw;                  raw += 4 * (size_t)d;
+  s.ringcnt = (int*)raw;              raw += 4 * (size_t)R;
+  s.sel = (short*)raw;                raw += smem_align4(2 * (size_t)L);
+  s.pf = raw;                         raw += smem_align4((size_t)L);
+  s.ringforbid = raw;
+}
 
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
 #pragma unroll
@@ -80,10 +97,12 @@ __device__ __forceinline__ bool forbidden_at(const bd_step_args& p, const Smem& 
 }
 
 __global__ __launch_bounds__(64) void sample_step_kernel(bd_step_args p) {
-  __shared__ Smem s;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Smem s;
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
   const int L = p.L, V = p.V, d = p.d;
+  smem_carve(s, smem_raw, L, V, d, p.R > 0 ? p.R : 1);
   const int CH = (L + 63) / 64;  // contiguous positions per lane
   const int l0 = lane * CH;
   long long* ids_g = p.ids + (size_t)b * L;
@@ -335,22 +354,33 @@ __global__ __launch_bounds__(64) void sample_step_kernel(bd_step_args p) {
       }
       __syncthreads();
     }
+    if (!logits_mode) {
+      // logits of this row: the wave walks the vocabulary, every lane multiplies its 8-feature slices of
+      // the weight row with the hidden row (coalesced 16-byte loads, independent across v), a wave sum
+      // completes the dot product and lane v % 64 keeps it in s.row[v]
+      for (int v = 0; v < V; ++v) {
+        const unsigned short* wr = wout + (size_t)v * d;
+        float part = 0.f;
+        for (int k = lane * 8; k < d; k += 512) {
+          const u32x4 w = *(const u32x4*)(wr + k);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            part += __uint_as_float(w[e] << 16) * s.h[k + 2 * e];
+            part += __uint_as_float(w[e] & 0xffff0000u) * s.h[k + 2 * e + 1];
+          }
+        }
+        part = bd_wave_sum(part);
+        if (lane == (v & 63)) s.row[v] = part;
+      }
+      __syncthreads();
+    }
     float best = -INFINITY; int idx = -1;
     for (int v = lane; v < V; v += 64) {
       float x;
       if (logits_mode) {
         x = lg[(size_t)pos * V + v];
       } else {
-        const unsigned short* wr = wout + (size_t)v * d;
-        float acc = 0.f;
-        for (int k = 0; k < d; k += 8) {
-          const u32x4 w = *(const u32x4*)(wr + k);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            acc += __uint_as_float(w[e] << 16) * s.h[k + 2 * e];
-            acc += __uint_as_float(w[e] & 0xffff0000u) * s.h[k + 2 * e + 1];
-          }
-        }
+        const float acc = s.row[v];
         if (lg) lg[(size_t)pos * V + v] = acc;  // raw dump for replay
         x = acc / p.temperature;
         if ((pflag & PF_BOOST) && v == p.boost_id) x = 100.0f;
@@ -633,7 +663,9 @@ extern "C" int bd_sample_step(const bd_step_args* a, void* stream) {
   if (p.variant & BD_VB_URGENCY)
     BD_REQUIRE(p.boost_id >= 0 && p.boost_id < p.V, "bd_sample_step: bad boost id");
   if (p.B == 0) return BD_OK;
-  hipLaunchKernelGGL(sample_step_kernel, dim3(p.B), dim3(64), 0, (hipStream_t)stream, p);
+  const size_t lds = smem_bytes(p.L, p.V, p.d, p.R > 0 ? p.R : 1);
+  BD_REQUIRE(lds <= 64 * 1024, "bd_sample_step: working set of %zu bytes per sequence exceeds LDS", lds);
+  hipLaunchKernelGGL(sample_step_kernel, dim3(p.B), dim3(64), lds, (hipStream_t)stream, p);
   return bd_check_launch("bd_sample_step");
 }
 
