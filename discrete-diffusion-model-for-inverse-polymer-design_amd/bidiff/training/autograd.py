@@ -17,8 +17,17 @@ import torch
 from .. import _lib
 
 
+_STREAM = [None]
+
+
+def _enter():
+    """Called on entry of every autograd forward / backward of this module: looks the current HIP stream up once
+    (about 9 us through torch) for the fifty-odd launches that follow."""
+    _STREAM[0] = _lib.stream_handle()
+
+
 def _s():
-    return _lib.stream_handle()
+    return _STREAM[0]
 
 
 _SIDE = {}
@@ -104,7 +113,7 @@ class _TrainWeights:
             raise NotImplementedError(f"bidiff: num_heads * padded head_dim = {aw} must be a multiple of 128")
         self.qfix = (dhp / dh) ** 0.5
         self.vpad = (V + 127) // 128 * 128
-        self.ptr_key = tuple(p.data_ptr() for p in model.parameters())
+        self.ptr_key = tuple(p.data_ptr() for p in model._params())
         self.jobs = None
         if dhp == dh:
             self._build_persistent(model)
@@ -194,7 +203,7 @@ def _train_weights(model):
     tw = getattr(model, "_train_w", None)
     if tw is not None and tw[0] == key:
         return tw[1]
-    if tw is not None and tw[1].ptr_key == tuple(p.data_ptr() for p in model.parameters()):
+    if tw is not None and tw[1].ptr_key == tuple(p.data_ptr() for p in model._params()):
         tw[1].refresh(model)          # same storage, new values: one launch
         model._train_w = (key, tw[1])
         return tw[1]
@@ -206,6 +215,7 @@ def _train_weights(model):
 class _BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, ids, timesteps, keymask, *params):
+        _enter()
         lib = _lib.lib()
         B, L = ids.shape
         M = B * L
@@ -259,6 +269,7 @@ class _BackboneFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dlogits):
+        _enter()
         lib = _lib.lib()
         model, tw, drop = ctx.model, ctx.tw, ctx.drop
         ids, timesteps, keymask = ctx.ids, ctx.timesteps, ctx.keymask
@@ -271,7 +282,7 @@ class _BackboneFn(torch.autograd.Function):
         # has a dense fp32 .grad (FlatAdamW binds them to one flat buffer) they add straight into it
         # and autograd gets None for the parameters: no per-parameter zero fill, no AccumulateGrad
         # add. Otherwise fresh zero buffers are returned to autograd the usual way.
-        params = list(model.parameters())
+        params = list(model._params())
         direct = all(p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous()
                      and p.grad.device == dev for p in params if p.requires_grad)
         grads = {}
@@ -298,71 +309,89 @@ class _BackboneFn(torch.autograd.Function):
         dh_buf = torch.empty(M, d, dtype=bf, device=dev)
         _gemm(dl, tw.woutT, None, dh_buf, M, d, d, tw.vpad, d, 0)
         dx = torch.empty(M, d, device=dev)
-        # every LayerNorm backward also emits the bf16 gradient the next branch reads (with the fc2-output
-        # dropout of that branch folded in), so dx is not read again just to be cast
         n_layers = len(model.layers)
-        dy = torch.empty(M, d, dtype=bf, device=dev)        # gradient of the feed-forward branch output
-        dy2 = torch.empty(M, d, dtype=bf, device=dev)       # gradient of the attention branch output
-        _ln_bwd(dh_buf, ctx.x_last, ctx.stf, model.final_norm.weight, None, dx, gbuf(model.final_norm.weight),
-                gbuf(model.final_norm.bias), M, d, dx_bf16=dy if n_layers else None, drop=drop,
-                site=max(0, 4 * (n_layers - 1) + 3))
-
-        du = torch.empty(M, F, dtype=bf, device=dev)
         aw, dh, dhp, padded = tw.aw, tw.dh, tw.dhp, tw.dhp != tw.dh
 
-        # The weight-gradient GEMMs feed nothing further down the chain, so they run on a second stream
-        # beside the data-gradient chain (their atomic drains and tails overlap with its kernels). A
-        # buffer they read is not overwritten before they are done (event per buffer).
+        # The weight-gradient GEMMs feed nothing further down the chain, so they run on a second stream beside
+        # the data-gradient chain (their atomic drains and tails overlap with its kernels). Stream-to-stream
+        # waits are the expensive host calls here (about 27 us each), so a layer's four weight-gradient launches
+        # are handed over together at the end of the layer: one wait of the second stream on the main one. The
+        # gradient buffers they read rotate (two sets, three for the feed-forward branch gradient that a layer
+        # writes for the next one), and a layer begins by waiting for the hand-over of two layers before: one wait
+        # of the main stream. The last layer hands over launch by launch so that no tail is left behind it.
         main = torch.cuda.current_stream(dev)
         side = None if padded else _side_stream(dev)
-        last_read = {}
+        main_h = _STREAM[0]
+        side_h = C.c_void_p(side.cuda_stream) if side is not None else None
+        nb = 2 if side is not None else 1
+        dyb = [torch.empty(M, d, dtype=bf, device=dev) for _ in range(3 if side is not None else 1)]   # feed-forward branch
+        dy2b = [torch.empty(M, d, dtype=bf, device=dev) for _ in range(nb)]                            # attention branch
+        dub = [torch.empty(M, F, dtype=bf, device=dev) for _ in range(nb)]
+        dqkvb = [torch.empty(M, 3 * aw, dtype=bf, device=dev) for _ in range(nb)]
+        pending, handed = [], {}
 
-        def wgrad_side(dY, X, dW, N, K, db):
-            if side is None:
-                return _wgrad(dY, X, dW, M, N, K, db=db)
+        def hand_over(li):
+            if not pending:
+                return
             ready = torch.cuda.Event()
             ready.record(main)
             side.wait_event(ready)
-            with torch.cuda.stream(side):
-                _wgrad(dY, X, dW, M, N, K, db=db)
-                done = torch.cuda.Event()
-                done.record(side)
-            last_read[dY.data_ptr()] = done
+            _STREAM[0] = side_h              # the launch helpers take their stream from here
+            try:
+                for job in pending:
+                    _wgrad(*job)
+            finally:
+                _STREAM[0] = main_h
+            pending.clear()
+            done = torch.cuda.Event()
+            done.record(side)
+            handed[li] = done
 
-        def before_write(buf):
-            ev = last_read.pop(buf.data_ptr(), None)
-            if ev is not None:
-                main.wait_event(ev)
+        def wgrad_side(li, dY, X, dW, N, K, db):
+            if side is None:
+                return _wgrad(dY, X, dW, M, N, K, db=db)
+            pending.append((dY, X, dW, M, N, K, db))
+            if li == 0:
+                hand_over(li)
+
+        # every LayerNorm backward also emits the bf16 gradient the next branch reads (with the fc2-output
+        # dropout of that branch folded in), so dx is not read again just to be cast
+        top = (n_layers - 1) % len(dyb) if n_layers else 0
+        _ln_bwd(dh_buf, ctx.x_last, ctx.stf, model.final_norm.weight, None, dx, gbuf(model.final_norm.weight),
+                gbuf(model.final_norm.bias), M, d, dx_bf16=dyb[top] if n_layers else None, drop=drop,
+                site=max(0, 4 * (n_layers - 1) + 3))
+
         datt = torch.empty(M, aw, dtype=bf, device=dev)
-        dqkv = torch.empty(M, 3 * aw, dtype=bf, device=dev)
         delta = torch.empty(B, H, L, device=dev)
         for li, blk, w, s in zip(reversed(range(len(model.layers))), reversed(model.layers), reversed(tw.layers),
                                  reversed(ctx.saved)):
             a = blk.attn
+            ev = handed.pop(li + 2, None)
+            if ev is not None:
+                main.wait_event(ev)      # this layer's buffer set (and the buffer it writes for the next) are free
+            dy, dy_next = dyb[li % len(dyb)], dyb[(li - 1) % len(dyb)]
+            dy2, du, dqkv = dy2b[li % nb], dub[li % nb], dqkvb[li % nb]
             # x_out = x_mid + drop(fc2(drop(gelu(fc1(LN2(x_mid))))))
-            wgrad_side(dy, s["a"], gbuf(blk.ffn.fc2.weight), d, F, gbuf(blk.ffn.fc2.bias))
-            before_write(du)
+            wgrad_side(li, dy, s["a"], gbuf(blk.ffn.fc2.weight), d, F, gbuf(blk.ffn.fc2.bias))
             _gemm(dy, w["w2T"], None, du, M, F, F, d, F, 4, aux_in=s["u"], drop=drop, site=4 * li + 2)
-            wgrad_side(du, s["h2"], gbuf(blk.ffn.fc1.weight), F, d, gbuf(blk.ffn.fc1.bias))
+            wgrad_side(li, du, s["h2"], gbuf(blk.ffn.fc1.weight), F, d, gbuf(blk.ffn.fc1.bias))
             _gemm(du, w["w1T"], None, dh_buf, M, d, d, F, d, 0)
-            before_write(dy2)
             _ln_bwd(dh_buf, s["x_mid"], s["st2"], blk.norm2.weight, dx, dx, gbuf(blk.norm2.weight), gbuf(blk.norm2.bias), M, d,
                     dx_bf16=dy2)
             # x_mid = x_in + out_proj(attention(qkv(LN1(x_in))))
             if not padded:
-                wgrad_side(dy2, s["att"], gbuf(a.out_proj.weight), d, d, gbuf(a.out_proj.bias))
+                wgrad_side(li, dy2, s["att"], gbuf(a.out_proj.weight), d, d, gbuf(a.out_proj.bias))
             else:       # gradient of the zero-padded weight, real columns added to the parameter's
                 tmp = zeros(d, aw)
                 _wgrad(dy2, s["att"], tmp, M, d, aw, db=gbuf(a.out_proj.bias))
                 gbuf(a.out_proj.weight).view(d, H, dh).add_(tmp.view(d, H, dhp)[:, :, :dh])
             _gemm(dy2, w["woT"], None, datt, M, aw, aw, d, aw, 0)
-            before_write(dqkv)
             _ck(lib.bd_attention_bwd_drop(_lib.ptr(s["qkv"]), _lib.ptr(keymask), _lib.ptr(s["att"]), _lib.ptr(datt),
                                           _lib.ptr(s["lse"]), _lib.ptr(delta), _lib.ptr(dqkv), B, L, H, aw // H,
                                           _dp(drop), 4 * li + 1, _s()), "bd_attention_bwd")
             projs = (a.q_proj, a.k_proj, a.v_proj)
             if not padded:      # the three row segments of the stacked gradient, one launch
-                wgrad_side(dqkv, s["h1"], [gbuf(pr.weight) for pr in projs], 3 * aw, d, [gbuf(pr.bias) for pr in projs])
+                wgrad_side(li, dqkv, s["h1"], [gbuf(pr.weight) for pr in projs], 3 * aw, d, [gbuf(pr.bias) for pr in projs])
             else:   # rows of the padded projections; the q rows were scaled by qfix in the forward
                 tw_, tb_ = zeros(3, aw, d), zeros(3, aw)
                 _wgrad(dqkv, s["h1"], [tw_[0], tw_[1], tw_[2]], M, 3 * aw, d, db=[tb_[0], tb_[1], tb_[2]])
@@ -371,10 +400,10 @@ class _BackboneFn(torch.autograd.Function):
                     gbuf(proj.weight).view(H, dh, d).add_(tw_[i].view(H, dhp, d)[:, :dh], alpha=f)
                     gbuf(proj.bias).view(H, dh).add_(tb_[i].view(H, dhp)[:, :dh], alpha=f)
             _gemm(dqkv, w["wqkvT"], None, dh_buf, M, d, d, 3 * aw, d, 0)
-            if li > 0:
-                before_write(dy)
             _ln_bwd(dh_buf, s["x_in"], s["st1"], blk.norm1.weight, dx, dx, gbuf(blk.norm1.weight), gbuf(blk.norm1.bias), M, d,
-                    dx_bf16=dy if li > 0 else None, drop=drop, site=max(0, 4 * (li - 1) + 3))
+                    dx_bf16=dy_next if li > 0 else None, drop=drop, site=max(0, 4 * (li - 1) + 3))
+            if side is not None:
+                hand_over(li)
         if drop is not None:
             _ck(lib.bd_dropout_f32(_lib.ptr(dx), _lib.ptr(dx), M, d, _dp(drop), 0, _s()), "bd_dropout_f32")
         _ck(lib.bd_embed_bwd(_lib.ptr(dx), _lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(gbuf(model.token_embedding.weight)),
@@ -398,15 +427,16 @@ def backbone_forward_train(model, input_ids, timesteps, attention_mask):
     timesteps = model._check_inputs(input_ids, timesteps)
     ids = input_ids.to(torch.long).contiguous()
     keymask = model._keymask_bytes(attention_mask, ids)
-    for p in model.parameters():
+    for p in model._params():
         if p.dtype != torch.float32 or not p.is_contiguous():
             raise RuntimeError("bidiff training path expects contiguous fp32 parameters")
-    return _BackboneFn.apply(model, ids, timesteps, keymask, *model.parameters())
+    return _BackboneFn.apply(model, ids, timesteps, keymask, *model._params())
 
 
 class _MaskedCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, targets, indicator, attention_mask):
+        _enter()
         V = logits.shape[-1]
         lg = logits.contiguous().view(-1, V)
         M = lg.shape[0]
@@ -426,6 +456,7 @@ class _MaskedCE(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
+        _enter()
         lg, tg, ind, lse, sums = ctx.saved_tensors
         M, V = lg.shape
         g = gout.reshape(1).float().contiguous()

@@ -79,8 +79,9 @@ class FlatAdamW(torch.optim.Optimizer):
                                       float(g["eps"]), float(g["weight_decay"]), float(bc1), float(bc2_sqrt),
                                       _lib.ptr(ss), float(max_norm or 0.0), _lib.stream_handle())
         _lib.check(rc, "bd_adamw_step")
+        step_t = torch.tensor(float(self._step))
         for p in self._params:
-            self.state[p]["step"] = torch.tensor(float(self._step))
+            self.state[p]["step"] = step_t
         _lib.bump_weights_generation()   # parameters changed behind torch's back: refresh bf16 copies
         return None
 
