@@ -385,14 +385,16 @@ __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* sm
     asm volatile("" : "+v"(voff[k]));
   }
   const unsigned ldsw = (unsigned)(size_t)(lds_void*)smem + wave * 1024;
+  auto dma_piece = [&](const unsigned char* unit_src, unsigned unit_lds, int k) {
+    asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"
+                 ::"s"(unit_lds), "i"(k * 4096), "v"(voff[k]), "s"(unit_src)
+                 : "memory", "m0", "scc");
+  };
   auto issue_unit = [&](int u) {
     const unsigned char* const unit_src = p.wpack + (size_t)u * UNIT;
     const unsigned unit_lds = ldsw + (u % RING) * UNIT;
 #pragma unroll
-    for (int k = 0; k < PER_UNIT; ++k)
-      asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"
-                   ::"s"(unit_lds), "i"(k * 4096), "v"(voff[k]), "s"(unit_src)
-                   : "memory", "m0", "scc");
+    for (int k = 0; k < PER_UNIT; ++k) dma_piece(unit_src, unit_lds, k);
   };
 
   // ---- LayerNorm of the wave's 32 rows -> bf16 operands xln[kb] (row / column = token c,
@@ -445,10 +447,9 @@ __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* sm
   // before the barrier), so reading u + 1 may start during the tail of u, and (b) nobody reads
   // unit u - 1 any more, so unit u + 2 is issued into that slot.
   bf16x8 wf[NT];
-  auto mid_sync = [&](int u) {
+  auto mid_sync = [&]() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (u + 2 < NUNITS) issue_unit(u + 2);
   };
   // WEIGHT_IS_A: tile = W_frag * op (rows = weight rows), else tile = op * W_frag (rows = tokens).
   auto run_unit = [&](int u, auto weight_is_a, auto last_unit, f32x16 t, const bf16x8 (&op)[NT]) -> f32x16 {
@@ -456,9 +457,17 @@ __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* sm
     constexpr bool LAST = decltype(last_unit)::value;
     unsigned bc = lds0 + (u % RING) * UNIT, bn = lds0 + ((u + 1) % RING) * UNIT;
     asm volatile("" : "+v"(bc), "+v"(bn));
+    // unit u + 2 goes out piece by piece, one every second step of the unit's second half: a burst of all pieces
+    // of all four waves at the barrier queues up behind the CU's address path (64 B per clock: 64 cycles per piece)
+    const bool more = u + 2 < NUNITS;
+    const unsigned char* const next_src = p.wpack + (size_t)(u + 2) * UNIT;
+    const unsigned next_lds = ldsw + ((u + 2) % RING) * UNIT;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-      if (i == MID) mid_sync(u);
+      if (i == MID) mid_sync();
+      if (i >= MID && (i - MID) % 2 == 0 && (i - MID) / 2 < PER_UNIT) {
+        if (more) dma_piece(next_src, next_lds, (i - MID) / 2);
+      }
       const int j = i + LOOK;
       if (j < NT) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[j]) : "v"(bc), "i"(j * 1024));
       else if (!LAST) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[j - NT]) : "v"(bn), "i"((j - NT) * 1024));
