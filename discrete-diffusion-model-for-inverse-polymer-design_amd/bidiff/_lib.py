@@ -115,6 +115,9 @@ SIGNATURES = {
                                         C.c_uint, VP]),
     "bd_embed": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP]),
     "bd_layernorm": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_float, VP]),
+    "bd_gemm_f32": (C.c_int, [VP, C.c_longlong, VP, C.c_longlong, VP, VP, VP, C.c_longlong, C.c_int, C.c_int, C.c_int,
+                              C.c_int, VP]),
+    "bd_attention_f32": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "bd_gemm_bf16": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "bd_gemm_bf16_aux": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "bd_masked_ce_fwd": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, VP]),

@@ -104,6 +104,10 @@ class DiffusionBackbone(nn.Module):
         self._init_weights()
         self._packed = _Packed()
         self._ws = None
+        # "bf16": bf16 MFMA GEMMs with fp32 accumulation (logits within 2e-2 of the reference's fp32 forward);
+        # "fp32": every product in fp32 on the f32-input MFMA (within 1e-5), inference only, about 12x slower
+        self.compute_dtype = "bf16"
+        self._packed32 = None
         # Training dropout: keep decisions are a function of (dropout_seed, forward-pass counter,
         # site, element). dropout_seed None = drawn from torch's CPU generator at the first
         # training forward (so torch.manual_seed fixes it) and offset by the process rank.
@@ -305,6 +309,71 @@ class DiffusionBackbone(nn.Module):
             return attention_mask
         return (attention_mask != 0).to(torch.uint8).contiguous()
 
+    def _fp32_weights(self):
+        """Stacked q|k|v weight and bias (one GEMM for the three projections), rebuilt when a parameter changed."""
+        key = self._pack_key()
+        pk = self._packed32
+        if pk is not None and pk[0] == key:
+            return pk[1]
+        layers = []
+        for blk in self.layers:
+            a = blk.attn
+            layers.append((torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).detach().float().contiguous(),
+                           torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0).detach().float().contiguous()))
+        self._packed32 = (key, layers)
+        return layers
+
+    def _forward_fp32(self, ids, timesteps, keymask, want_hidden, want_logits, upto=None):
+        """The forward in fp32: the reference's operation sequence (backbone.py:215-257 with the blocks of
+        :120-129), one kernel per operation. Returns (final-norm hidden fp32 [B,L,d] or the residual stream after
+        ``upto`` blocks, logits fp32 or None)."""
+        L_ = _lib.lib()
+        st = _lib.stream_handle()
+        B, L = ids.shape
+        M, d, F, V, H = B * L, self.hidden_size, self.ffn_hidden_size, self.vocab_size, self.num_heads
+        dev = ids.device
+        if d % 16 or F % 16:
+            raise ValueError("bidiff fp32 mode needs hidden and ffn sizes that are multiples of 16")
+        for p_ in self._params():
+            if p_.dtype != torch.float32 or not p_.is_contiguous():
+                raise RuntimeError("bidiff fp32 mode expects contiguous fp32 parameters")
+
+        def gemm(A, W, bias, out, N, K, epi=0, resid=None):
+            _lib.check(L_.bd_gemm_f32(_lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(bias), _lib.ptr(resid), _lib.ptr(out), N,
+                                      M, N, K, epi, st), "bd_gemm_f32")
+
+        def ln(x, norm, out):
+            _lib.check(L_.bd_layernorm(_lib.ptr(x), _lib.ptr(norm.weight), _lib.ptr(norm.bias), None, _lib.ptr(out), None,
+                                       M, d, float(norm.eps), st), "bd_layernorm")
+
+        x = torch.empty(M, d, device=dev)
+        _lib.check(L_.bd_embed(_lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(self.token_embedding.weight),
+                               _lib.ptr(self.position_embedding.weight), _lib.ptr(self.timestep_embedding.weight),
+                               _lib.ptr(x), B, L, d, st), "bd_embed")
+        h = torch.empty(M, d, device=dev)
+        qkv = torch.empty(M, 3 * d, device=dev)
+        att = torch.empty(M, d, device=dev)
+        u = torch.empty(M, F, device=dev)
+        n_blocks = self.num_layers if upto is None else upto
+        for blk, (wqkv, bqkv) in list(zip(self.layers, self._fp32_weights()))[:n_blocks]:
+            ln(x, blk.norm1, h)
+            gemm(h, wqkv, bqkv, qkv, 3 * d, d)
+            _lib.check(L_.bd_attention_f32(_lib.ptr(qkv), _lib.ptr(keymask), _lib.ptr(att), B, L, H, d // H, st),
+                       "bd_attention_f32")
+            gemm(att, blk.attn.out_proj.weight, blk.attn.out_proj.bias, x, d, d, epi=2, resid=x)
+            ln(x, blk.norm2, h)
+            gemm(h, blk.ffn.fc1.weight, blk.ffn.fc1.bias, u, F, d, epi=1)
+            gemm(u, blk.ffn.fc2.weight, blk.ffn.fc2.bias, x, d, F, epi=2, resid=x)
+        if upto is not None:
+            return x.view(B, L, d), None
+        ln(x, self.final_norm, h)
+        logits = None
+        if want_logits:
+            logits = torch.empty(M, V, device=dev)
+            gemm(h, self.output_proj.weight, None, logits, V, d)
+            logits = logits.view(B, L, V)
+        return (h.view(B, L, d) if want_hidden else None), logits
+
     def run_forward(self, input_ids, timesteps, keymask, want_hidden=True, want_logits=False,
                     hidden_out=None, logits_out=None):
         """One inference forward on the current stream. keymask: uint8 [B,L] or None.
@@ -312,6 +381,18 @@ class DiffusionBackbone(nn.Module):
         timesteps = self._check_inputs(input_ids, timesteps)
         ids = input_ids.to(torch.long).contiguous()
         B, L = ids.shape
+        if self.compute_dtype == "fp32":
+            # fp32 mode: hidden comes back in fp32 (not the bf16 rows of the fused path)
+            hidden, logits = self._forward_fp32(ids, timesteps, keymask, want_hidden, want_logits)
+            if hidden_out is not None and hidden is not None:
+                hidden_out.copy_(hidden)
+                hidden = hidden_out
+            if logits_out is not None and logits is not None:
+                logits_out.copy_(logits)
+                logits = logits_out
+            return hidden, logits
+        if self.compute_dtype != "bf16":
+            raise ValueError(f"compute_dtype must be 'bf16' or 'fp32', got {self.compute_dtype!r}")
         pk = self.packed()
         ws, need = self._workspace(pk, B, L, ids.device)
         if want_hidden and hidden_out is None:
@@ -351,6 +432,9 @@ class DiffusionBackbone(nn.Module):
                 raise IndexError(f"layer_idx {layer_idx} out of range for {self.num_layers} layers")
             timesteps = self._check_inputs(input_ids, timesteps)
             B, L = input_ids.shape
+            if self.compute_dtype == "fp32":
+                return self._forward_fp32(input_ids.to(torch.long).contiguous(), timesteps, keymask, False, False,
+                                          upto=layer_idx + 1)[0]
             pk = self.packed()
             ws, need = self._workspace(pk, B, L, input_ids.device)
             ids = input_ids.to(torch.long).contiguous()
@@ -376,6 +460,15 @@ class DiffusionBackbone(nn.Module):
         keymask = self._keymask_bytes(attention_mask, input_ids)
         hidden, _ = self.run_forward(input_ids, timesteps, keymask, want_hidden=True, want_logits=False)
         B, L = input_ids.shape
+        if self.compute_dtype == "fp32":        # the pooling kernel reads bf16 rows; fp32 rows are pooled by torch
+            if pooling == "cls":
+                return hidden[:, 0, :].contiguous()
+            if attention_mask is None:
+                return hidden.mean(dim=1) if pooling == "mean" else hidden.max(dim=1)[0]
+            m = attention_mask.unsqueeze(-1).to(hidden.dtype)
+            if pooling == "mean":
+                return (hidden * m).sum(dim=1) / m.sum(dim=1).clamp(min=1)
+            return hidden.masked_fill(m == 0, float("-inf")).max(dim=1)[0]
         am = None if attention_mask is None else attention_mask.to(torch.long).contiguous()
         out = torch.empty(B, self.hidden_size, dtype=torch.float32, device=input_ids.device)
         rc = _lib.lib().bd_pool_hidden(_lib.ptr(hidden), _lib.ptr(am), _lib.ptr(out), B, L, self.hidden_size,

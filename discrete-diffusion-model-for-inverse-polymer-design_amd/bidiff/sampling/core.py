@@ -187,7 +187,8 @@ class ReverseSampler:
             dump = torch.zeros(B, L, tt.V, dtype=torch.float32, device=dev)
         for t in steps:
             ts = torch.full((B,), t, device=dev, dtype=torch.long)
-            full = (t == 1 and self.use_constraints)
+            # fp32 compute mode: full fp32 logits every step (the chosen-row shortcut reads bf16 hidden rows)
+            full = (t == 1 and self.use_constraints) or getattr(backbone, "compute_dtype", "bf16") == "fp32"
             a.t = t
             a.ktable = ktab[t].data_ptr()
             if self.record is not None:

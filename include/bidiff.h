@@ -49,6 +49,22 @@ int bd_embed(const long long* ids, const long long* timesteps, const float* tok_
 int bd_layernorm(const float* x, const float* gamma, const float* beta, void* out_bf16,
                  float* out_f32, float* stats, int M, int d, float eps, void* stream);
 
+/* ---- fp32 compute mode (logits within 1e-5 of the reference's fp32 forward; the reference samples without
+ * autocast, src/sampling/sampler.py). Embeddings and LayerNorm are bd_embed / bd_layernorm (fp32 output).
+ *
+ * out[M,N] = A[M,K] W[N,K]^T (+ bias[N]) in fp32 on the f32-input MFMA; epilogue 0: that, 1: erf-GELU of it,
+ * 2: resid + it (out may be resid). K must be a multiple of 16, lda / ldw multiples of 4, A and W 16-byte aligned.
+ * replaces nn.Linear at src/model/backbone.py:26-29 (q/k/v/out projections), :93-94 (feed-forward), :197 (head)
+ * and nn.GELU at :95 when the model computes in fp32. */
+int bd_gemm_f32(const float* A, long long lda, const float* W, long long ldw, const float* bias,
+                const float* resid, float* out, long long ldc, int M, int N, int K, int epilogue,
+                void* stream);
+/* out[b,l,h*dh:(h+1)*dh] = softmax(q k^T / sqrt(dh) + key padding) v in fp32; qkv rows are [q | k | v] of width
+ * 3 H dh; keymask uint8 [B,L] (0 = padded key) or null; rows whose keys are all padded come out as zeros.
+ * dh in {32, 64, 96, 128}, L <= 512. replaces F.scaled_dot_product_attention at src/model/backbone.py:60-66. */
+int bd_attention_f32(const float* qkv, const unsigned char* keymask, float* out, int B, int L, int H,
+                     int dh, void* stream);
+
 /* C[M,n] = A[M,K] (bf16) * W[n_pad,K]^T (bf16) with a fused epilogue
  *   0: out bf16 = acc + bias          (q/k/v projections fused as one [3d,d] weight)
  *   1: out bf16 = gelu_erf(acc + bias)
