@@ -62,9 +62,15 @@ def train_bench(dev, rank, world, steps, warmup, batch=256, L=128):
     model = DiscreteMaskingDiffusion(bb, num_steps=T, mask_token_id=1, pad_token_id=0, bos_token_id=2,
                                      eos_token_id=3).to(dev).train()
     model.corruption_rng = "philox"
+    staged = world > 1 and dist.get_backend() == "gloo"      # rehearsal on one device: exchange through the host
     if world > 1:
         for t_ in list(model.parameters()):
-            dist.broadcast(t_.data, src=0)
+            if staged:
+                c_ = t_.data.cpu()
+                dist.broadcast(c_, src=0)
+                t_.data.copy_(c_)
+            else:
+                dist.broadcast(t_.data, src=0)
     opt = FlatAdamW(model.parameters(), lr=3e-4, weight_decay=0.01)
     rs = np.random.RandomState(1 + rank)
     lens = np.clip(np.round(rs.normal(38.5, 15.0, size=batch)), 12, L).astype(np.int64)
@@ -80,7 +86,12 @@ def train_bench(dev, rank, world, steps, warmup, batch=256, L=128):
         out = model(ids_d, attn_d)
         out["loss"].backward()
         if world > 1:
-            allreduce_mean_(opt.flat_grad, world)
+            if staged:
+                c_ = opt.flat_grad.cpu()
+                allreduce_mean_(c_, world)
+                opt.flat_grad.copy_(c_)
+            else:
+                allreduce_mean_(opt.flat_grad, world)
         opt.step(max_norm=1.0)
         opt.zero_grad()
         return out["loss"]
@@ -128,10 +139,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the N > 1 logic on a one-GPU box: BD_BENCH_REHEARSAL=1 puts every rank on device 0 and
+    # exchanges over gloo (RCCL refuses two ranks on one device); never set by the driver
+    rehearsal = os.environ.get("BD_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
+        import faulthandler
+        faulthandler.dump_traceback_later(120, exit=True)      # a stuck rehearsal names its line
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)
+        if rehearsal:
+            dist.init_process_group(backend="gloo", init_method="env://")
+        else:
+            dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)
 
     from bidiff import _lib
     from bidiff.model.backbone import DiffusionBackbone
@@ -197,7 +218,10 @@ def main():
     if args.train_steps > 0:
         del ids
         torch.cuda.empty_cache()
-        train = train_bench(dev, rank, world, args.train_steps, 5)
+        try:
+            train = train_bench(dev, rank, world, args.train_steps, 5)
+        except Exception as exc:      # the sampling line (the headline metric) is still reported
+            train = {"error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
         total_seqs = world * B * args.steps
