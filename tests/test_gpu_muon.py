@@ -128,7 +128,7 @@ def test_flat_muon_adamw_follows_reference_trajectory(gpu_device, tmp_path):
                 if named[n].ndim == 2 and "layers." in n:        # Muon: bf16 Newton-Schulz vs the fp32 golden
                     assert rel(got - start[n], want32 - start[n]) < 1e-1, (step, n)
                     assert cos(got - start[n], want32 - start[n]) > 0.995, (step, n)
-                    assert rel(got - start[n], snaps16[step][n] - start[n]) < 3e-2, (step, n)
+                    assert rel(got - start[n], snaps16[step][n] - start[n]) < 5e-2, (step, n)   # measured 0.019-0.022: the clip norm's atomics move last bits, bf16 Newton-Schulz amplifies them
                 else:                                            # AdamW group: fp32 arithmetic
                     assert torch.allclose(got, want32, rtol=1e-5, atol=2e-6), (step, n)
     # state_dict layout of the reference: group 0 adamw (step / exp_avg / exp_avg_sq), group 1 muon (momentum_buffer)
@@ -159,7 +159,7 @@ def test_flat_muon_adamw_follows_reference_trajectory(gpu_device, tmp_path):
         # the global-norm reduction adds block partials with atomics (order-dependent last bits), so
         # the two runs agree to rounding (fp32 for AdamW, bf16 inside Newton-Schulz), not bit for bit
         if p.ndim == 2 and "layers." in n:
-            assert rel(p.detach() - before[n], q.detach() - before[n]) < 2e-2, n
+            assert rel(p.detach() - before[n], q.detach() - before[n]) < 5e-2, n
         else:
             assert torch.allclose(p, q, rtol=1e-5, atol=1e-7), n
 
