@@ -83,7 +83,8 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
   constexpr int NF = 2 * NT;                  // fragments (= MFMAs) per chunk iteration
   constexpr int LOOK = 8;                     // fragment reads in flight ahead of their MFMA
   constexpr int SYNC = NF - LOOK;             // step of the iteration's barrier
-  constexpr int DMA_EVERY = 4;                // one piece every fourth step: 2 PER_UNIT pieces per iteration
+  constexpr int DMA_EVERY = 4;                // one piece per four steps on average: 2 PER_UNIT pieces per iteration
+  constexpr int DMA_GROUP = 2;                // issued in groups of this many
   static_assert(NT % 8 == 0 && NF / DMA_EVERY == 2 * PER_UNIT && PER_UNIT >= 2, "unsupported width");
   float* const sb1 = (float*)(smem + RING * UNIT);     // F + 64 floats
   typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
@@ -277,14 +278,19 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
       }
-      if (i % DMA_EVERY == 0) {
-        const int slot = i / DMA_EVERY;                       // 0 .. 2 PER_UNIT - 1
-        if (i >= SYNC) {
-          if (odd_next) dma_piece(src_next, lds_next, slot - SYNC / DMA_EVERY);
-        } else if (slot < PER_UNIT - 2) {
-          if (odd_rest) dma_piece(src_odd, lds_odd, slot + 2);
-        } else {
-          if (even_all) dma_piece(src_even, lds_even, slot - (PER_UNIT - 2));
+      if (i % (DMA_EVERY * DMA_GROUP) == 0) {
+        // DMA_GROUP pieces back to back: the stream into the CU runs at 17 B/clk with one piece in flight per wave,
+        // 23 with two, 24.7 at best (tools_prof/micro/stream_rate.hip)
+#pragma unroll
+        for (int g = 0; g < DMA_GROUP; ++g) {
+          const int slot = i / DMA_EVERY + g;                 // 0 .. 2 PER_UNIT - 1
+          if (slot >= SYNC / DMA_EVERY) {
+            if (odd_next) dma_piece(src_next, lds_next, slot - SYNC / DMA_EVERY);
+          } else if (slot < PER_UNIT - 2) {
+            if (odd_rest) dma_piece(src_odd, lds_odd, slot + 2);
+          } else {
+            if (even_all) dma_piece(src_even, lds_even, slot - (PER_UNIT - 2));
+          }
         }
       }
       // wait for fragment i: younger reads in flight are the LOOK - 1 behind it, plus, in the tail, the four bias reads
@@ -457,16 +463,16 @@ __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* sm
     constexpr bool LAST = decltype(last_unit)::value;
     unsigned bc = lds0 + (u % RING) * UNIT, bn = lds0 + ((u + 1) % RING) * UNIT;
     asm volatile("" : "+v"(bc), "+v"(bn));
-    // unit u + 2 goes out piece by piece, one every second step of the unit's second half: a burst of all pieces
-    // of all four waves at the barrier queues up behind the CU's address path (64 B per clock: 64 cycles per piece)
+    // unit u + 2 goes out in pairs of pieces over the unit's second half: a burst of all pieces of all four waves at
+    // the barrier queues up behind the CU's memory path, single pieces leave it half idle (17 B/clk against 23)
     const bool more = u + 2 < NUNITS;
     const unsigned char* const next_src = p.wpack + (size_t)(u + 2) * UNIT;
     const unsigned next_lds = ldsw + ((u + 2) % RING) * UNIT;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       if (i == MID) mid_sync();
-      if (i >= MID && (i - MID) % 2 == 0 && (i - MID) / 2 < PER_UNIT) {
-        if (more) dma_piece(next_src, next_lds, (i - MID) / 2);
+      if (i >= MID && (i - MID) % 4 == 0 && (i - MID) / 2 < PER_UNIT) {      // in pairs: two in flight per wave
+        if (more) { dma_piece(next_src, next_lds, (i - MID) / 2); dma_piece(next_src, next_lds, (i - MID) / 2 + 1); }
       }
       const int j = i + LOOK;
       if (j < NT) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[j]) : "v"(bc), "i"(j * 1024));
