@@ -358,19 +358,26 @@ __global__ __launch_bounds__(64) void sample_step_kernel(bd_step_args p) {
       // logits of this row: the wave walks the vocabulary, every lane multiplies its 8-feature slices of
       // the weight row with the hidden row (coalesced 16-byte loads, independent across v), a wave sum
       // completes the dot product and lane v % 64 keeps it in s.row[v]
-      for (int v = 0; v < V; ++v) {
-        const unsigned short* wr = wout + (size_t)v * d;
-        float part = 0.f;
+      // four vocabulary rows per round: their loads are in flight together and the four wave sums interleave
+      for (int v0 = 0; v0 < V; v0 += 4) {
+        float part[4] = {0.f, 0.f, 0.f, 0.f};
         for (int k = lane * 8; k < d; k += 512) {
-          const u32x4 w = *(const u32x4*)(wr + k);
+          u32x4 w[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            part += __uint_as_float(w[e] << 16) * s.h[k + 2 * e];
-            part += __uint_as_float(w[e] & 0xffff0000u) * s.h[k + 2 * e + 1];
-          }
+          for (int u = 0; u < 4; ++u) w[u] = *(const u32x4*)(wout + (size_t)min(v0 + u, V - 1) * d + k);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              part[u] += __uint_as_float(w[u][e] << 16) * s.h[k + 2 * e];
+              part[u] += __uint_as_float(w[u][e] & 0xffff0000u) * s.h[k + 2 * e + 1];
+            }
         }
-        part = bd_wave_sum(part);
-        if (lane == (v & 63)) s.row[v] = part;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) part[u] += __shfl_xor(part[u], o, 64);
+        if (lane < 4 && v0 + lane < V) s.row[v0 + lane] = lane == 0 ? part[0] : lane == 1 ? part[1] : lane == 2 ? part[2] : part[3];
       }
       __syncthreads();
     }
