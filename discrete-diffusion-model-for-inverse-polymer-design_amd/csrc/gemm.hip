@@ -151,11 +151,21 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& p, int m, int nb, f
       x[0] += v[4 * j4 + 0]; x[1] += v[4 * j4 + 1]; x[2] += v[4 * j4 + 2]; x[3] += v[4 * j4 + 3];
       *(f32x4*)(o + 4 * j4) = x;
     }
-  } else {  // EPI_F32, ragged N
+  } else {  // EPI_F32, ragged N: rows of n_real floats are only 4-byte aligned, the 16-byte stores say so
+    typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
     float* o = (float*)p.out + (size_t)m * p.ldc;
+    if (nb + 16 <= p.n_real) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
-      if (nb + j < p.n_real) o[nb + j] = v[j];
+      for (int j4 = 0; j4 < 4; ++j4) {
+        f32x4_u x;
+        x[0] = v[4 * j4]; x[1] = v[4 * j4 + 1]; x[2] = v[4 * j4 + 2]; x[3] = v[4 * j4 + 3];
+        *(f32x4_u*)(o + nb + 4 * j4) = x;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (nb + j < p.n_real) o[nb + j] = v[j];
+    }
   }
 }
 
