@@ -7,6 +7,7 @@
 // them for its residual add - 196 KB per workgroup that the same CU wrote a few tens of
 // microseconds earlier, served from L2 / Infinity Cache. HBM sees the ids, the weights and the
 // final hidden states; between layers nothing drains, no kernel boundary, no tail.
+#include <cstdlib>
 #include "bd_common.h"
 #include "bd_prof.h"
 #include "bidiff.h"
@@ -190,7 +191,13 @@ extern "C" int bd_backbone_mega(const bd_backbone_desc* desc, const long long* i
       else ncu = 256;
     }
     a.stagger_blocks = (B >= 4 * ncu) ? ncu : 0;
-    a.stagger_units = 3;
+    static int units = -1;
+    if (units < 0) {
+      const char* e = getenv("BD_MEGA_STAGGER");      // tuning knob: phase shift between the CUs' first workgroups
+      units = e ? atoi(e) : 3;
+      if (units < 0 || units > 64) units = 3;
+    }
+    a.stagger_units = units;
   }
   const int d = c.d, dh = d / c.n_heads;
   void* tok = bd_prof_on() ? bd_prof_begin(stream) : nullptr;
