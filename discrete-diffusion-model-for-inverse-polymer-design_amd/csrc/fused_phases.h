@@ -84,7 +84,7 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
   constexpr int LOOK = 8;                     // fragment reads in flight ahead of their MFMA
   constexpr int SYNC = NF - LOOK;             // step of the iteration's barrier
   constexpr int DMA_EVERY = 4;                // one piece per four steps on average: 2 PER_UNIT pieces per iteration
-  constexpr int DMA_GROUP = 2;                // issued in groups of this many
+  constexpr int DMA_GROUP = 2;                // issued in groups of this many (4 and 6 measure the same)
   static_assert(NT % 8 == 0 && NF / DMA_EVERY == 2 * PER_UNIT && PER_UNIT >= 2, "unsupported width");
   float* const sb1 = (float*)(smem + RING * UNIT);     // F + 64 floats
   typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
@@ -278,19 +278,19 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
       }
-      if (i % (DMA_EVERY * DMA_GROUP) == 0) {
-        // DMA_GROUP pieces back to back: the stream into the CU runs at 17 B/clk with one piece in flight per wave,
-        // 23 with two, 24.7 at best (tools_prof/micro/stream_rate.hip)
+      // DMA_GROUP pieces back to back (the stream into the CU runs at 17 B/clk with one piece in flight per wave, 23
+      // with two, 24.7 at best: tools_prof/micro/stream_rate.hip); the two pieces of the next odd unit wait for the
+      // barrier at step SYNC
 #pragma unroll
-        for (int g = 0; g < DMA_GROUP; ++g) {
-          const int slot = i / DMA_EVERY + g;                 // 0 .. 2 PER_UNIT - 1
-          if (slot >= SYNC / DMA_EVERY) {
-            if (odd_next) dma_piece(src_next, lds_next, slot - SYNC / DMA_EVERY);
-          } else if (slot < PER_UNIT - 2) {
-            if (odd_rest) dma_piece(src_odd, lds_odd, slot + 2);
-          } else {
-            if (even_all) dma_piece(src_even, lds_even, slot - (PER_UNIT - 2));
-          }
+      for (int slot = 0; slot < 2 * PER_UNIT; ++slot) {
+        const int at = slot >= SYNC / DMA_EVERY ? SYNC : (slot / DMA_GROUP) * (DMA_GROUP * DMA_EVERY);
+        if (at != i) continue;
+        if (slot >= SYNC / DMA_EVERY) {
+          if (odd_next) dma_piece(src_next, lds_next, slot - SYNC / DMA_EVERY);
+        } else if (slot < PER_UNIT - 2) {
+          if (odd_rest) dma_piece(src_odd, lds_odd, slot + 2);
+        } else {
+          if (even_all) dma_piece(src_even, lds_even, slot - (PER_UNIT - 2));
         }
       }
       // wait for fragment i: younger reads in flight are the LOOK - 1 behind it, plus, in the tail, the four bias reads
