@@ -207,20 +207,23 @@ def test_attention_backward(gpu_device, dh, Hh, L):
     assert got.view(B, L, 3 * d)[2].abs().max().item() == 0.0, "fully padded sequence: zero gradients"
 
 
-def test_embedding_backward(gpu_device):
+@pytest.mark.parametrize("B,L,d,V", [(8, 20, 128, 39), (5, 300, 384, 7), (3, 1, 64, 39)])
+def test_embedding_backward(gpu_device, B, L, d, V):
+    """Rows of a sequence are merged per token before the atomics: few distinct tokens over 300 positions (more
+    positions than threads in the rank sort), a single position, and the small default."""
     dev = gpu_device
-    B, L, d, V, T = 8, 20, 128, 39, 21
+    T = 21
     g = torch.Generator().manual_seed(4)
     ids = torch.randint(0, V, (B, L), generator=g)
     t = torch.randint(0, T, (B,), generator=g)
     dx = torch.randn(B * L, d, generator=g)
-    dtok, dpos, dtim = torch.zeros(V, d, device=dev), torch.zeros(64, d, device=dev), torch.zeros(T, d, device=dev)
+    dtok, dpos, dtim = torch.zeros(V, d, device=dev), torch.zeros(max(64, L), d, device=dev), torch.zeros(T, d, device=dev)
     a, b, c = ids.to(dev), t.to(dev), dx.to(dev)
     _lib.check(_lib.lib().bd_embed_bwd(_lib.ptr(c), _lib.ptr(a), _lib.ptr(b), _lib.ptr(dtok), _lib.ptr(dpos), _lib.ptr(dtim),
                                        B, L, d, 0, _s()), "embed bwd")
     torch.cuda.synchronize()
     tok = torch.nn.Embedding(V, d, padding_idx=0)
-    pos, tim = torch.nn.Embedding(64, d), torch.nn.Embedding(T, d)
+    pos, tim = torch.nn.Embedding(max(64, L), d), torch.nn.Embedding(T, d)
     (tok(ids) + pos(torch.arange(L))[None] + tim(t)[:, None]).backward(dx.view(B, L, d))
     assert rel(dtok.cpu(), tok.weight.grad) < 1e-5 and dtok[0].abs().max().item() == 0.0
     assert rel(dpos.cpu(), pos.weight.grad) < 1e-5 and rel(dtim.cpu(), tim.weight.grad) < 1e-5
