@@ -1,7 +1,7 @@
 // Fused self-attention block of a pre-norm transformer layer, one sequence per workgroup:
 //     x <- x + Wo * Attention(LayerNorm(x) Wq^T, LayerNorm(x) Wk^T, LayerNorm(x) Wv^T) + bo
 // in ONE kernel (sequence length <= 128). q, k, v, the scores and the attention output never
-// exist in memory: the residual rows are read (twice) and written once, the weights stream from
+// exist in memory: the residual rows are read once and written once, the weights stream from
 // L2 through LDS.
 //
 // A 256-thread workgroup owns a sequence, each wave 32 tokens (one 32-wide MFMA block). The
@@ -14,9 +14,10 @@
 //              the A fragments of the score / value products; they go to LDS, all waves read
 //              them)   S = K Q^T   P = softmax over keys (exp2; the log2(e)/sqrt(dh) scale is
 //              folded into Wq by the host)   O^T = V^T P^T (rounded tiles = B operands of Wo)
-//   then:      acc = Wo O^T over all heads, + x + bo, store.
-// Every unit of the stream is one 32x32 output tile: d/16 fragments -> d/16 MFMAs on one
-// accumulator. Key padding enters as the initial value (0 / -1e30) of the score accumulators.
+//              rows += Wo[:, head's columns] O^T (the rows stay in the accumulation registers)
+//   then:      + bo, store.
+// Every q / k / v unit of the stream is one 32x32 output tile: d/16 fragments -> d/16 MFMAs on one
+// accumulator; a unit of a head's Wo slice covers d/dh output tiles with dh/16 fragments each. Key padding enters as the initial value (0 / -1e30) of the score accumulators.
 // A query whose keys are all masked gives an all-zero attention output (as bd_attention_fwd).
 #include "bd_common.h"
 #include "bd_prof.h"
@@ -49,16 +50,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const float* xrow = p.x + row * D + 4 * (lane >> 5);
   f32x16 acc[NT / 2];
   load_rows(acc, xrow);
-  attn_phase<NT, DH>(ph, smem, acc, xrow);
+  attn_phase<NT, DH>(ph, smem, acc);
   if (tok < L) store_rows(acc, p.out + row * D + 4 * (lane >> 5));
 }
 
 // Packs the q|k|v projection (bf16 [3d, d], LayerNorm gamma folded, q rows scaled by
 // log2(e) / sqrt(dh)) and the output projection (bf16 [d, d]) into the fragment stream.
-// Fragment = 64 lanes x 8 bf16, lane = 32 h + c; unit = d/16 fragments = one output tile.
-//   units of head hd: [q tiles | k tiles | v tiles], tile dt, fragment kb:
+// Fragment = 64 lanes x 8 bf16, lane = 32 h + c; unit = d/16 fragments.
+//   units of head hd: [q tiles | k tiles | v tiles | Wo slice], dh/32 units each.
+//   q / k / v tile dt, fragment kb:
 //       W[sec d + hd dh + 32 dt + c][32 (kb / 2) + 8 (2 (kb % 2) + e / 4) + 4 h + e % 4]
-//   then unit T of Wo, fragment kbg = hd (dh/16) + 2 dt + kk:
+//   Wo slice: fragment g = (unit within the slice) d/16 + f covers output tile T = g / (dh/16) and
+//   k-fragment 2 dt + kk = g % (dh/16) of the head's columns:
 //       Wo[32 T + c][hd dh + 32 dt + 8 (2 kk + e / 4) + 4 h + e % 4]
 __global__ void attn_pack_kernel(const unsigned short* __restrict__ wqkv, const unsigned short* __restrict__ wo,
                                  unsigned short* __restrict__ out, int d, int H) {
@@ -70,14 +73,13 @@ __global__ void attn_pack_kernel(const unsigned short* __restrict__ wqkv, const 
     const long fr = i >> 9;
     const int f = fr % NT, u = fr / NT;
     unsigned short v;
-    if (u < 3 * H * DT) {
-      const int hd = u / (3 * DT), r = u % (3 * DT), sec = r / DT, dt = r % DT;
+    const int hd = u / (4 * DT), r = u % (4 * DT), sec = r / DT, dt = r % DT;
+    if (sec < 3) {
       const int k = 32 * (f >> 1) + 8 * (2 * (f & 1) + (e >> 2)) + 4 * h + (e & 3);
       v = wqkv[(size_t)(sec * d + hd * DH + 32 * dt + c) * d + k];
     } else {
-      const int T = u - 3 * H * DT;
-      const int hd = f / KBO, rr = f % KBO, dt = rr >> 1, kk = rr & 1;
-      v = wo[(size_t)(32 * T + c) * d + hd * DH + 32 * dt + 8 * (2 * kk + (e >> 2)) + 4 * h + (e & 3)];
+      const int g = dt * NT + f, T = g / KBO, rr = g % KBO, kt = rr >> 1, kk = rr & 1;
+      v = wo[(size_t)(32 * T + c) * d + hd * DH + 32 * kt + 8 * (2 * kk + (e >> 2)) + 4 * h + (e & 3)];
     }
     out[i] = v;
   }

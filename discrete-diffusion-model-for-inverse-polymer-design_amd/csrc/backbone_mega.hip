@@ -1,12 +1,10 @@
 // Whole denoiser forward in ONE launch, one sequence (L <= 128) per workgroup:
 //   embeddings -> n_layers x [attention phase, feed-forward phase] -> final LayerNorm -> bf16 hidden.
 // Sequences never interact, so a workgroup carries its sequence through every layer without any
-// grid-wide synchronisation. The residual rows stay in registers from phase to phase (the
-// attention phase's output layout IS the feed-forward phase's input layout, and vice versa); once
-// per layer they are also written to a scratch row buffer because the attention phase re-reads
-// them for its residual add - 196 KB per workgroup that the same CU wrote a few tens of
-// microseconds earlier, served from L2 / Infinity Cache. HBM sees the ids, the weights and the
-// final hidden states; between layers nothing drains, no kernel boundary, no tail.
+// grid-wide synchronisation. The residual rows stay in accumulation registers from the embeddings
+// to the final LayerNorm (the attention phase's output layout IS the feed-forward phase's input
+// layout, and vice versa, and both phases add to the rows in place). HBM sees the ids, the weights
+// and the final hidden states; between layers nothing drains, no kernel boundary, no tail.
 #include <cstdlib>
 #include "bd_common.h"
 #include "bd_prof.h"
@@ -38,7 +36,7 @@ struct MegaArgs {
   const float* time_emb;
   const float* lnf_g;
   const float* lnf_b;
-  float* xbuf;                   // [B * L, d] scratch rows
+  float* xbuf;                   // unused (kept for the entry point's signature)
   unsigned short* hidden;        // [B * L, d] bf16 final-norm output
   int B, L, F, n_layers;
   float eps;
@@ -58,7 +56,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const bool valid = tok < L;
   const int tokc = valid ? tok : L - 1;                 // lanes past the sequence shadow its last row
   const size_t row = (size_t)seq * L + tokc;
-  float* const xrow = p.xbuf + row * D + 4 * h;
   stagger_start(p.stagger_blocks, p.stagger_units);
 
   // ---- embeddings: x = (token + position) + timestep, straight into accumulator layout
@@ -91,8 +88,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 #pragma nounroll
   for (int l = 0; l < p.n_layers; ++l) {
-    // the rows go to memory for the attention phase's residual re-read (same lane, same address)
-    if (valid) store_rows(acc, xrow);
     const MegaLayer& lw = p.layers[l];
     ap.wpack = lw.attn_pack; ap.bq = lw.bq; ap.bo = lw.bo; ap.bo_fold = lw.bo_fold;
     fp.wpack = lw.ffn_pack; fp.b1 = lw.b1; fp.b2 = lw.b2;
@@ -100,7 +95,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    attn_phase<NT, DH>(ap, smem, acc, xrow);
+    attn_phase<NT, DH>(ap, smem, acc);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();

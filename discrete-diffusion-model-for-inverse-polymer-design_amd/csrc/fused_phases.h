@@ -344,8 +344,9 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
 
 // ---------------------------------------------------------------------------------------------
 // Attention phase for one sequence: acc (in) = the wave's 32 residual rows (token 32 wave + c of the
-// sequence), acc (out) = rows + Wo MHA(LN(rows)) + bias. The rows must also be in memory at xrow
-// (this lane's row pointer, + 4 h floats): they are re-read for the residual add at the end.
+// sequence), acc (out) = rows + Wo MHA(LN(rows)) + bias. The rows never leave the accumulation
+// registers: every head adds its slice of the output projection to them as soon as its attention
+// output exists.
 // smem: 3 units + K and V fragments (2 x 256 dh bytes... 128 keys) + d + 128 floats.
 struct AttnPhase {
   const unsigned char* wpack;   // packed weight stream (bd_attn_pack_weights)
@@ -358,7 +359,7 @@ struct AttnPhase {
 };
 
 template <int NT, int DH>
-__device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* smem, f32x16 (&acc)[NT / 2], const float* xrow) {
+__device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* smem, f32x16 (&acc)[NT / 2]) {
   constexpr int D = NT * 16;
   constexpr int NT32 = NT / 2;
   constexpr int H = D / DH;
@@ -367,8 +368,8 @@ __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* sm
   constexpr int UNIT = NT * 1024;
   constexpr int RING = 3;
   constexpr int PER_UNIT = NT / 4;
-  constexpr int QKV_UNITS = 3 * H * DT;
-  constexpr int NUNITS = QKV_UNITS + NT32;
+  constexpr int NUNITS = 4 * H * DT;             // per head: DT units each of q, k, v and of the head's Wo slice
+  constexpr int WO_TILES = NT / KBO;             // output tiles covered by one unit of a Wo slice
   constexpr int KV_BYTES = 128 * DH * 2;
   constexpr int LOOK = NT >= 16 ? 8 : 4;      // fragment reads in flight
   constexpr int MID = NT / 2;                 // MFMA index of a unit's barrier
@@ -457,10 +458,9 @@ __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* sm
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   };
-  // WEIGHT_IS_A: tile = W_frag * op (rows = weight rows), else tile = op * W_frag (rows = tokens).
-  auto run_unit = [&](int u, auto weight_is_a, auto last_unit, f32x16 t, const bf16x8 (&op)[NT]) -> f32x16 {
-    constexpr bool WEIGHT_IS_A = decltype(weight_is_a)::value;
-    constexpr bool LAST = decltype(last_unit)::value;
+  // One unit: NT fragments -> NT MFMAs, step(i, fragment) issues the MFMA of fragment i. The reads of the first LOOK
+  // fragments of the following unit go out during the tail (after the last unit they fetch stale bytes nobody uses).
+  auto stream_unit = [&](int u, auto&& step) {
     unsigned bc = lds0 + (u % RING) * UNIT, bn = lds0 + ((u + 1) % RING) * UNIT;
     asm volatile("" : "+v"(bc), "+v"(bn));
     // unit u + 2 goes out in pairs of pieces over the unit's second half: a burst of all pieces of all four waves at
@@ -476,12 +476,19 @@ __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* sm
       }
       const int j = i + LOOK;
       if (j < NT) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[j]) : "v"(bc), "i"(j * 1024));
-      else if (!LAST) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[j - NT]) : "v"(bn), "i"((j - NT) * 1024));
-      // reads younger than fragment i that may stay in flight
-      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(wf[i]) : "i"((j < NT || !LAST) ? LOOK : NT - 1 - i));
-      if (WEIGHT_IS_A) t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], op[i], t, 0, 0, 0);
-      else t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[i], wf[i], t, 0, 0, 0);
+      else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[j - NT]) : "v"(bn), "i"((j - NT) * 1024));
+      // LOOK younger reads may stay in flight
+      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(wf[i]) : "i"(LOOK));
+      step(i, wf[i]);
     }
+  };
+  // WEIGHT_IS_A: tile = W_frag * op (rows = weight rows), else tile = op * W_frag (rows = tokens).
+  auto run_unit = [&](int u, auto weight_is_a, f32x16 t, const bf16x8 (&op)[NT]) -> f32x16 {
+    constexpr bool WEIGHT_IS_A = decltype(weight_is_a)::value;
+    stream_unit(u, [&](int i, const bf16x8& w) {
+      if (WEIGHT_IS_A) t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, op[i], t, 0, 0, 0);
+      else t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op[i], w, t, 0, 0, 0);
+    });
     return t;
   };
   // accumulator initialised with per-ROW values table[8 q + 4 h + e] (rows of a D tile)
@@ -515,9 +522,6 @@ __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* sm
     for (int i = 0; i < LOOK; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[i]) : "v"(b0), "i"(i * 1024));
   }
 
-  bf16x8 oall[NT];              // attention output of all heads as B operands of the Wo product
-#pragma unroll
-  for (int i = 0; i < NT; ++i) oall[i] = xln[0];   // defined values; every entry is overwritten
   bool dead = false;            // every key of the sequence masked (same for all queries and heads)
 
   int u = 0;
@@ -532,7 +536,7 @@ __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* sm
     bf16x8 qb[KBO];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
-      const f32x16 t = run_unit(u, std::true_type{}, std::false_type{}, qinit[dt], xln);
+      const f32x16 t = run_unit(u, std::true_type{}, qinit[dt], xln);
       qb[2 * dt] = pack_half(t, 0);
       qb[2 * dt + 1] = pack_half(t, 1);
       ++u;
@@ -540,7 +544,7 @@ __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* sm
     // ---- K^T tiles: rounded halves are the A fragments (row = key) of S = K Q^T
 #pragma nounroll
     for (int dt = 0; dt < DT; ++dt) {
-      const f32x16 t = run_unit(u, std::true_type{}, std::false_type{}, zero16, xln);
+      const f32x16 t = run_unit(u, std::true_type{}, zero16, xln);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
         *(lds_frag_w)(size_t)(ldsK + ((wave * KBO + 2 * dt + kk) << 10)) = pack_half(t, kk);
@@ -549,7 +553,7 @@ __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* sm
     // ---- V tiles (rows = tokens): rounded halves are the A fragments (row = dh) of O^T = V^T P^T
 #pragma nounroll
     for (int dt = 0; dt < DT; ++dt) {
-      const f32x16 t = run_unit(u, std::false_type{}, std::false_type{}, zero16, xln);
+      const f32x16 t = run_unit(u, std::false_type{}, zero16, xln);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
         *(lds_frag_w)(size_t)(ldsV + ((dt * 8 + 2 * wave + kk) << 10)) = pack_half(t, kk);
@@ -626,30 +630,26 @@ __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* sm
         onew[2 * dt + 1] = pack_half(o, 1);
       }
     }
-    // heads land in order: shift the array down by one head and append
+    // ---- rows += Wo[:, this head's columns] O^T: DT units of WO_TILES output tiles x KBO fragments each
 #pragma unroll
-    for (int i = 0; i + KBO < NT; ++i) oall[i] = oall[i + KBO];
-#pragma unroll
-    for (int i = 0; i < KBO; ++i) oall[NT - KBO + i] = onew[i];
+    for (int w = 0; w < DT; ++w) {
+      stream_unit(u, [&](int i, const bf16x8& wfrag) {
+        const int T = w * WO_TILES + i / KBO;
+        acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag, onew[i % KBO], acc[T], 0, 0, 0);
+      });
+      ++u;
+    }
   }
+  // the reads issued past the last unit
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-  // ---- out = Wo O^T: one unit per 32-feature tile
-#pragma unroll
-  for (int T = 0; T < NT32; ++T) {
-    if (T + 1 < NT32) acc[T] = run_unit(u, std::true_type{}, std::false_type{}, zero16, oall);
-    else acc[T] = run_unit(u, std::true_type{}, std::true_type{}, zero16, oall);
-    ++u;
-  }
-
-  // ---- + residual (re-read) + bias
+  // ---- + bias
 #pragma unroll
   for (int T = 0; T < NT32; ++T)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f32x4 xv = *(const f32x4*)(xrow + 32 * T + 8 * q);
       const f32x4 b = *(const f32x4*)((dead ? p.bo : p.bo_fold) + 32 * T + 8 * q + 4 * h);
-      acc[T][4 * q + 0] = acc[T][4 * q + 0] + xv[0] + b[0]; acc[T][4 * q + 1] = acc[T][4 * q + 1] + xv[1] + b[1];
-      acc[T][4 * q + 2] = acc[T][4 * q + 2] + xv[2] + b[2]; acc[T][4 * q + 3] = acc[T][4 * q + 3] + xv[3] + b[3];
+      acc[T][4 * q + 0] += b[0]; acc[T][4 * q + 1] += b[1]; acc[T][4 * q + 2] += b[2]; acc[T][4 * q + 3] += b[3];
     }
 }
 
