@@ -162,7 +162,7 @@ extern "C" int bd_backbone_mega(const bd_backbone_desc* desc, const long long* i
                                 const unsigned char* keymask, int B, int L, float* xbuf, void* hidden_out,
                                 void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  BD_REQUIRE(desc && ids && timesteps && xbuf && hidden_out, "bd_backbone_mega: null operand");
+  BD_REQUIRE(desc && ids && timesteps && hidden_out, "bd_backbone_mega: null operand");
   BD_REQUIRE(B > 0, "bd_backbone_mega: B=%d", B);
   BD_REQUIRE(bd_backbone_mega_supported(desc, L), "bd_backbone_mega: unsupported model shape or L=%d", L);
   const bd_backbone_desc& c = *desc;

@@ -187,8 +187,9 @@ int bd_backbone_forward(const bd_backbone_desc* desc, const long long* ids,
 
 /* The same forward as ONE kernel launch, one sequence per workgroup, when bd_backbone_mega_supported
  * (every layer carries the fused-kernel weight streams, L <= 128, n_layers <= 32): embeddings, all
- * layers and the final LayerNorm; the residual rows stay in registers from phase to phase. xbuf
- * [B*L, d] fp32 is scratch, hidden_out [B*L, d] bf16 the final-norm output. bd_backbone_forward
+ * layers and the final LayerNorm; the residual rows stay in registers from the embeddings to the
+ * final LayerNorm. xbuf is not used any more (any non-null pointer; kept so that the signature
+ * stays), hidden_out [B*L, d] bf16 is the final-norm output. bd_backbone_forward
  * takes this route by itself (environment BD_MEGA=0 turns it off). */
 int bd_backbone_mega_supported(const bd_backbone_desc* desc, int L);
 int bd_backbone_mega(const bd_backbone_desc* desc, const long long* ids, const long long* timesteps,
