@@ -146,6 +146,8 @@ SIGNATURES = {
     "bd_ffn_fused": (C.c_int, [VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_float, VP]),
     "bd_attn_block_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "bd_attn_pack_bytes": (C.c_long, [C.c_int]),
+    "bd_attn_pack_bytes_heads": (C.c_long, [C.c_int, C.c_int]),
+    "bd_attn_block_width": (C.c_int, [C.c_int, C.c_int]),
     "bd_attn_pack_weights": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, VP]),
     "bd_attn_block_fused": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, VP]),
     "bd_attention_fwd": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),

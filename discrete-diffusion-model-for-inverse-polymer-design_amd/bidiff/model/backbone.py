@@ -236,21 +236,23 @@ class DiffusionBackbone(nn.Module):
                 lw.b_qkv_ln = f32(bqkv + wq32 @ blk.norm1.bias.float()).data_ptr()
                 # weight stream of the fused attention block: q rows (and bias) also carry the
                 # softmax scale log2(e) / sqrt(head_dim), see attn_block.hip
-                if dhp == dh and L_.bd_attn_block_supported(d, self.num_heads, 1):
-                    sc = math.log2(math.e) / math.sqrt(d // self.num_heads)
+                if L_.bd_attn_block_supported(d, self.num_heads, 1) and L_.bd_attn_block_width(d, self.num_heads) == aw:
+                    # the q rows already carry sqrt(padded / true) for the kernels that scale by 1 / sqrt(padded);
+                    # this stream wants log2(e) / sqrt(true head size) in total
+                    sc = math.log2(math.e) / math.sqrt(dh) / qfix
                     wa = (wq32 * blk.norm1.weight.float()[None, :]).clone()
                     ba = (bqkv + wq32 @ blk.norm1.bias.float()).clone()
-                    wa[:d] *= sc
-                    ba[:d] *= sc
+                    wa[:aw] *= sc
+                    ba[:aw] *= sc
                     wab = bf(wa)
-                    apack = torch.empty(L_.bd_attn_pack_bytes(d), dtype=torch.uint8, device=dev)
+                    apack = torch.empty(L_.bd_attn_pack_bytes_heads(d, self.num_heads), dtype=torch.uint8, device=dev)
                     keep.append(apack)
                     _lib.check(L_.bd_attn_pack_weights(wab.data_ptr(), lw.w_o, apack.data_ptr(), d, self.num_heads,
                                                        _lib.stream_handle()), "bd_attn_pack_weights")
                     lw.attn_pack = apack.data_ptr()
-                    lw.b_q_attn = f32(ba[:d]).data_ptr()
+                    lw.b_q_attn = f32(ba[:aw]).data_ptr()
                     # v bias: softmax rows sum to one, so it passes through attention unchanged
-                    lw.b_o_fold = f32(a.out_proj.bias.float() + a.out_proj.weight.float() @ ba[2 * d:]).data_ptr()
+                    lw.b_o_fold = f32(a.out_proj.bias.float() + wo32 @ ba[2 * aw:]).data_ptr()
                 w1 = blk.ffn.fc1.weight.float()
                 w1ln = bf(w1 * blk.norm2.weight.float()[None, :])
                 lw.w_fc1_ln = w1ln.data_ptr()

@@ -36,7 +36,7 @@ struct AttnArgs {
 };
 
 // (The phase itself lives in fused_phases.h.)
-template <int NT, int DH>   // NT = d / 16, DH = head dimension
+template <int NT, int DH, int H>   // NT = d / 16, H heads of DH (padded) features
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_block_kernel(AttnArgs p) {
   constexpr int D = NT * 16;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -50,23 +50,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const float* xrow = p.x + row * D + 4 * (lane >> 5);
   f32x16 acc[NT / 2];
   load_rows(acc, xrow);
-  attn_phase<NT, DH>(ph, smem, acc);
+  attn_phase<NT, DH, H>(ph, smem, acc);
   if (tok < L) store_rows(acc, p.out + row * D + 4 * (lane >> 5));
 }
 
-// Packs the q|k|v projection (bf16 [3d, d], LayerNorm gamma folded, q rows scaled by
-// log2(e) / sqrt(dh)) and the output projection (bf16 [d, d]) into the fragment stream.
+// Packs the q|k|v projection (bf16 [3 H dh, d], LayerNorm gamma folded, q rows scaled by
+// log2(e) / sqrt(true head size); dh = the padded head size, padded rows zero) and the output
+// projection (bf16 [d, H dh], padded columns zero) into the fragment stream.
 // Fragment = 64 lanes x 8 bf16, lane = 32 h + c; unit = d/16 fragments.
 //   units of head hd: [q tiles | k tiles | v tiles | Wo slice], dh/32 units each.
 //   q / k / v tile dt, fragment kb:
-//       W[sec d + hd dh + 32 dt + c][32 (kb / 2) + 8 (2 (kb % 2) + e / 4) + 4 h + e % 4]
+//       W[sec H dh + hd dh + 32 dt + c][32 (kb / 2) + 8 (2 (kb % 2) + e / 4) + 4 h + e % 4]
 //   Wo slice: fragment g = (unit within the slice) d/16 + f covers output tile T = g / (dh/16) and
 //   k-fragment 2 dt + kk = g % (dh/16) of the head's columns:
 //       Wo[32 T + c][hd dh + 32 dt + 8 (2 kk + e / 4) + 4 h + e % 4]
 __global__ void attn_pack_kernel(const unsigned short* __restrict__ wqkv, const unsigned short* __restrict__ wo,
-                                 unsigned short* __restrict__ out, int d, int H) {
-  const int NT = d / 16, DH = d / H, DT = DH / 32, KBO = DH / 16;
-  const long total = 2l * NT * NT * 512;
+                                 unsigned short* __restrict__ out, int d, int H, int DH) {
+  const int NT = d / 16, DT = DH / 32, KBO = DH / 16, AW = H * DH;
+  const long total = 4l * H * DT * NT * 512;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int e = i & 7, l = (i >> 3) & 63;
     const int c = l & 31, h = l >> 5;
@@ -76,40 +77,51 @@ __global__ void attn_pack_kernel(const unsigned short* __restrict__ wqkv, const 
     const int hd = u / (4 * DT), r = u % (4 * DT), sec = r / DT, dt = r % DT;
     if (sec < 3) {
       const int k = 32 * (f >> 1) + 8 * (2 * (f & 1) + (e >> 2)) + 4 * h + (e & 3);
-      v = wqkv[(size_t)(sec * d + hd * DH + 32 * dt + c) * d + k];
+      v = wqkv[(size_t)(sec * AW + hd * DH + 32 * dt + c) * d + k];
     } else {
       const int g = dt * NT + f, T = g / KBO, rr = g % KBO, kt = rr >> 1, kk = rr & 1;
-      v = wo[(size_t)(32 * T + c) * d + hd * DH + 32 * kt + 8 * (2 * kk + (e >> 2)) + 4 * h + (e & 3)];
+      v = wo[(size_t)(32 * T + c) * AW + hd * DH + 32 * kt + 8 * (2 * kk + (e >> 2)) + 4 * h + (e & 3)];
     }
     out[i] = v;
   }
 }
 
-template <int NT, int DH>
+template <int NT, int DH, int H = NT * 16 / DH>
 int launch_attn(const AttnArgs& a, hipStream_t stream) {
-  const size_t lds = attn_phase_lds(NT, DH);
-  hipFuncSetAttribute((const void*)attn_block_kernel<NT, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((attn_block_kernel<NT, DH>), dim3(a.B), dim3(256), lds, stream, a);
+  const size_t lds = attn_phase_lds(NT, DH, H);
+  hipFuncSetAttribute((const void*)attn_block_kernel<NT, DH, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((attn_block_kernel<NT, DH, H>), dim3(a.B), dim3(256), lds, stream, a);
   return bd_check_launch("bd_attn_block_fused");
 }
 
 }  // namespace
 
-extern "C" int bd_attn_block_supported(int d, int n_heads, int L) {
+// Head size the kernels run with: the true one, or the next of 32 / 64 / 128 with zero padding. 0 = no kernel.
+static int padded_head(int d, int n_heads) {
   if (n_heads <= 0 || d % n_heads) return 0;
   const int dh = d / n_heads;
-  const bool shape = (d == 384 && (dh == 128 || dh == 64)) || (d == 256 && (dh == 128 || dh == 64)) || (d == 128 && (dh == 64 || dh == 32));
-  return shape && L >= 1 && L <= 128;
+  const bool exact = (d == 384 && (dh == 128 || dh == 64)) || (d == 256 && (dh == 128 || dh == 64)) || (d == 128 && (dh == 64 || dh == 32));
+  if (exact) return dh;
+  if (d == 384 && n_heads == 8) return 64;      // 8 heads of 48: the reference's default backbone
+  return 0;
 }
 
+extern "C" int bd_attn_block_supported(int d, int n_heads, int L) {
+  return padded_head(d, n_heads) != 0 && L >= 1 && L <= 128;
+}
+
+extern "C" int bd_attn_block_width(int d, int n_heads) { return n_heads * padded_head(d, n_heads); }
+
 extern "C" long bd_attn_pack_bytes(int d) { return 8l * d * d; }
+
+extern "C" long bd_attn_pack_bytes_heads(int d, int n_heads) { return 8l * bd_attn_block_width(d, n_heads) * d; }
 
 extern "C" int bd_attn_pack_weights(const void* w_qkv, const void* w_o, void* out, int d, int n_heads, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   BD_REQUIRE(w_qkv && w_o && out, "bd_attn_pack_weights: null pointer");
   BD_REQUIRE(bd_attn_block_supported(d, n_heads, 128), "bd_attn_pack_weights: unsupported d=%d heads=%d", d, n_heads);
   hipLaunchKernelGGL(attn_pack_kernel, dim3(1024), dim3(256), 0, stream, (const unsigned short*)w_qkv,
-                     (const unsigned short*)w_o, (unsigned short*)out, d, n_heads);
+                     (const unsigned short*)w_o, (unsigned short*)out, d, n_heads, padded_head(d, n_heads));
   return bd_check_launch("bd_attn_pack_weights");
 }
 
@@ -131,10 +143,11 @@ extern "C" int bd_attn_block_fused(const float* x, float* out, const void* wpack
     }
     a.stagger_blocks = (B >= 4 * ncu) ? ncu : 0;   // only worth it when every CU runs several workgroups in a row
   }
-  const int dh = d / n_heads;
+  const int dh = padded_head(d, n_heads);
   void* tok = bd_prof_on() ? bd_prof_begin(stream) : nullptr;
   int rc;
-  if (d == 384 && dh == 128) rc = launch_attn<24, 128>(a, stream);
+  if (d == 384 && n_heads == 8) rc = launch_attn<24, 64, 8>(a, stream);
+  else if (d == 384 && dh == 128) rc = launch_attn<24, 128>(a, stream);
   else if (d == 384) rc = launch_attn<24, 64>(a, stream);
   else if (d == 256 && dh == 128) rc = launch_attn<16, 128>(a, stream);
   else if (d == 256) rc = launch_attn<16, 64>(a, stream);

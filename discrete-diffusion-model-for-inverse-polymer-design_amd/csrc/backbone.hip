@@ -94,7 +94,7 @@ int forward_impl(const bd_backbone_desc* desc, const long long* ids, const long 
   const bool pan_qkv = bd_gemm_panel_supported(3 * aw, d, 1) != 0;
   const bool pan_fc1 = bd_gemm_panel_supported(F, d, 1) != 0;
   const bool fused_ffn = bd_ffn_fused_supported(d, F) != 0;
-  const bool fused_attn = aw == d && bd_attn_block_supported(d, c.n_heads, L) != 0;
+  const bool fused_attn = bd_attn_block_supported(d, c.n_heads, L) != 0 && aw == bd_attn_block_width(d, c.n_heads);
   for (int i = 0; i < n_run; ++i) {
     const bd_layer_weights& lw = c.layers[i];
     // ---- x += out_proj(attention(ln1(x)))

@@ -44,7 +44,7 @@ struct MegaArgs {
   MegaLayer layers[MEGA_MAX_LAYERS];
 };
 
-template <int NT, int DH>
+template <int NT, int DH, int H>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void backbone_mega_kernel(MegaArgs p) {
   constexpr int D = NT * 16;
   constexpr int NT32 = NT / 2;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    attn_phase<NT, DH>(ap, smem, acc);
+    attn_phase<NT, DH, H>(ap, smem, acc);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -135,12 +135,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 }
 
-template <int NT, int DH>
+template <int NT, int DH, int H = NT * 16 / DH>
 int launch_mega(const MegaArgs& a, hipStream_t stream) {
-  const size_t la = attn_phase_lds(NT, DH), lf = ffn_phase_lds(NT, a.F);
+  const size_t la = attn_phase_lds(NT, DH, H), lf = ffn_phase_lds(NT, a.F);
   const size_t lds = la > lf ? la : lf;
-  hipFuncSetAttribute((const void*)backbone_mega_kernel<NT, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((backbone_mega_kernel<NT, DH>), dim3(a.B), dim3(256), lds, stream, a);
+  hipFuncSetAttribute((const void*)backbone_mega_kernel<NT, DH, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((backbone_mega_kernel<NT, DH, H>), dim3(a.B), dim3(256), lds, stream, a);
   return bd_check_launch("bd_backbone_mega");
 }
 
@@ -148,8 +148,9 @@ int launch_mega(const MegaArgs& a, hipStream_t stream) {
 
 extern "C" int bd_backbone_mega_supported(const bd_backbone_desc* c, int L) {
   if (c == nullptr || c->n_layers < 1 || c->n_layers > MEGA_MAX_LAYERS) return 0;
-  if (c->attn_width != 0 && c->attn_width != c->d) return 0;
   if (!bd_attn_block_supported(c->d, c->n_heads, L) || !bd_ffn_fused_supported(c->d, c->ffn)) return 0;
+  // the q | k | v width of the descriptor's weights must be the one the attention stream was packed for
+  if ((c->attn_width != 0 ? c->attn_width : c->d) != bd_attn_block_width(c->d, c->n_heads)) return 0;
   if (ffn_phase_lds(c->d / 16, c->ffn) > 160 * 1024) return 0;
   for (int i = 0; i < c->n_layers; ++i) {
     const bd_layer_weights& lw = c->layers[i];
@@ -194,10 +195,11 @@ extern "C" int bd_backbone_mega(const bd_backbone_desc* desc, const long long* i
     }
     a.stagger_units = units;
   }
-  const int d = c.d, dh = d / c.n_heads;
+  const int d = c.d, dh = bd_attn_block_width(d, c.n_heads) / c.n_heads;
   void* tok = bd_prof_on() ? bd_prof_begin(stream) : nullptr;
   int rc;
-  if (d == 384 && dh == 128) rc = launch_mega<24, 128>(a, stream);
+  if (d == 384 && c.n_heads == 8) rc = launch_mega<24, 64, 8>(a, stream);
+  else if (d == 384 && dh == 128) rc = launch_mega<24, 128>(a, stream);
   else if (d == 384) rc = launch_mega<24, 64>(a, stream);
   else if (d == 256 && dh == 128) rc = launch_mega<16, 128>(a, stream);
   else if (d == 256) rc = launch_mega<16, 64>(a, stream);

@@ -18,8 +18,8 @@ struct Gelu4 { float x[4], s[4], p[4]; };
 
 // bytes of LDS the phases need
 __host__ __device__ constexpr size_t ffn_phase_lds(int NT, int F) { return 6 * (size_t)NT * 1024 + ((size_t)F + 64) * 4; }
-__host__ __device__ constexpr size_t attn_phase_lds(int NT, int DH) {
-  return 3 * (size_t)NT * 1024 + 2 * (size_t)128 * DH * 2 + (size_t)NT * 16 * 4 + 128 * 4;
+__host__ __device__ constexpr size_t attn_phase_lds(int NT, int DH, int H) {
+  return 3 * (size_t)NT * 1024 + 2 * (size_t)128 * DH * 2 + (size_t)H * DH * 4 + 128 * 4;
 }
 
 // Loads / stores of the wave's 32 rows in accumulator layout: acc[T][4 q + e] = row[32 T + 8 q + 4 h + e]
@@ -348,10 +348,12 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
 // sequence), acc (out) = rows + Wo MHA(LN(rows)) + bias. The rows never leave the accumulation
 // registers: every head adds its slice of the output projection to them as soon as its attention
 // output exists.
-// smem: 3 units + K and V fragments (2 x 256 dh bytes... 128 keys) + d + 128 floats.
+// smem: 3 units + K and V fragments (2 x 256 dh bytes... 128 keys) + H dh + 128 floats.
+// H heads of DH features each; H DH may exceed d (heads zero-padded to a width the MFMA tiles divide: the padded
+// q / k features add nothing to the scores, the padded v features meet zero columns of Wo).
 struct AttnPhase {
   const unsigned char* wpack;   // packed weight stream (bd_attn_pack_weights)
-  const float* bq;              // [d]: q bias with LayerNorm beta folded, scaled like the q rows
+  const float* bq;              // [H dh]: q bias with LayerNorm beta folded, scaled like the q rows
   const float* bo;              // [d] output bias
   const float* bo_fold;         // [d] output bias + Wo * (v bias with LayerNorm beta folded)
   const unsigned char* keymask; // this SEQUENCE's byte mask [L] (non-zero = visible) or null
@@ -359,11 +361,11 @@ struct AttnPhase {
   float eps;
 };
 
-template <int NT, int DH>
+template <int NT, int DH, int H>
 __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* smem, f32x16 (&acc)[NT / 2]) {
   constexpr int D = NT * 16;
   constexpr int NT32 = NT / 2;
-  constexpr int H = D / DH;
+  constexpr int AW = H * DH;                  // width of q, k and v
   constexpr int DT = DH / 32;                 // 32-row tiles of a head's q / k / v
   constexpr int KBO = DH / 16;                // 16-wide k-blocks of a head
   constexpr int UNIT = NT * 1024;
@@ -375,11 +377,11 @@ __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* sm
   constexpr int LOOK = NT >= 16 ? 6 : 4;      // fragment reads in flight (6 measures 0.6 % faster than 8, 4 and 12 slower)
   constexpr int MID = NT / 2;                 // MFMA index of a unit's barrier (a third of the way: no difference)
   static_assert(MID <= NT - LOOK, "the barrier must precede the first read of the next unit");
-  static_assert(NT % 4 == 0 && DH % 32 == 0 && D % DH == 0, "unsupported shape");
+  static_assert(NT % 4 == 0 && DH % 32 == 0 && NT % KBO == 0 && AW >= D, "unsupported shape");
   unsigned char* const sK = smem + RING * UNIT;
   unsigned char* const sV = sK + KV_BYTES;
-  float* const sbias = (float*)(sV + KV_BYTES);        // d floats (q bias)
-  float* const smask = sbias + D;                  // 128 floats: 0 (visible) or -1e30
+  float* const sbias = (float*)(sV + KV_BYTES);        // H dh floats (q bias)
+  float* const smask = sbias + AW;                 // 128 floats: 0 (visible) or -1e30
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -411,7 +413,7 @@ __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* sm
   {
     issue_unit(0);
     issue_unit(1);
-    for (int i = tid; i < D; i += 256) sbias[i] = p.bq[i];
+    for (int i = tid; i < AW; i += 256) sbias[i] = p.bq[i];
     if (tid < 128) {
       const bool vis = tid < p.L && (p.keymask == nullptr || p.keymask[tid] != 0);
       smask[tid] = vis ? 0.f : -1e30f;

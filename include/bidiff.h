@@ -114,7 +114,13 @@ int bd_ffn_fused(const float* x, float* out, const void* wpack, const float* b1_
  * Replaces TransformerBlock.forward's  x + attn(ln1(x))  (src/model/backbone.py:126,
  * MultiHeadAttention.forward :38-72). */
 int bd_attn_block_supported(int d, int n_heads, int L);
-long bd_attn_pack_bytes(int d);
+/* Width H * dh' of q, k and v inside the fused block: dh' is the head size d / n_heads, or the next of 32 / 64 / 128
+ * when the kernels have no tiling for it (8 heads of 48 at d = 384 run as 8 heads of 64). The caller zero-pads the
+ * q | k | v rows ([3 H dh', d], head by head) and the columns of the output projection ([d, H dh']) and multiplies the
+ * q rows by log2(e) / sqrt(d / n_heads) (the true head size); the q bias has H dh' entries. 0 = unsupported. */
+int bd_attn_block_width(int d, int n_heads);
+long bd_attn_pack_bytes(int d);                       /* heads of 32 / 64 / 128 (width = d) */
+long bd_attn_pack_bytes_heads(int d, int n_heads);    /* any supported head count: 8 * width * d */
 int bd_attn_pack_weights(const void* w_qkv_folded_scaled, const void* w_o, void* wpack, int d, int n_heads,
                          void* stream);
 int bd_attn_block_fused(const float* x, float* out, const void* wpack, const float* b_q_folded_scaled,

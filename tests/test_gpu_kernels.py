@@ -342,15 +342,24 @@ def _attn_block_case(gpu_device, B, L, d, H, masked, seed):
     bf = bqkv + Wqkv @ bt
     wf[:d] *= scale
     bf[:d] *= scale
+    # heads the kernels have no tiling for run zero-padded: rows of q | k | v and columns of Wo, head by head
+    aw = lib.bd_attn_block_width(d, H)
+    dhp = aw // H
+    Wo_p = Wo
+    if dhp != dh:
+        wp = torch.zeros(3, H, dhp, d); wp[:, :, :dh] = wf.view(3, H, dh, d); wf = wp.view(3 * aw, d)
+        bp = torch.zeros(3, H, dhp); bp[:, :, :dh] = bf.view(3, H, dh); bf = bp.view(3 * aw)
+        Wo_p = torch.zeros(d, H, dhp); Wo_p[:, :, :dh] = Wo.view(d, H, dh); Wo_p = Wo_p.view(d, aw)
     wqkv_b = wf.bfloat16().to(gpu_device)
-    wo_b = Wo.bfloat16().to(gpu_device)
-    pack = torch.empty(lib.bd_attn_pack_bytes(d), dtype=torch.uint8, device=gpu_device)
+    wo_b = Wo_p.bfloat16().to(gpu_device)
+    assert lib.bd_attn_pack_bytes_heads(d, H) == 8 * aw * d and (aw != d or lib.bd_attn_pack_bytes(d) == 8 * d * d)
+    pack = torch.empty(lib.bd_attn_pack_bytes_heads(d, H), dtype=torch.uint8, device=gpu_device)
     _lib.check(lib.bd_attn_pack_weights(_lib.ptr(wqkv_b), _lib.ptr(wo_b), _lib.ptr(pack), d, H, _s()), "attn pack")
     xd = x.to(gpu_device)
     out = torch.empty_like(xd)
-    bfd = bf[:d].contiguous().to(gpu_device)
+    bfd = bf[:aw].contiguous().to(gpu_device)
     bod = bo.to(gpu_device)
-    bofd = (bo + Wo @ bf[2 * d:]).to(gpu_device)
+    bofd = (bo + Wo_p @ bf[2 * aw:]).to(gpu_device)
     kmd = km.to(gpu_device) if km is not None else None
     _lib.check(lib.bd_attn_block_fused(_lib.ptr(xd), _lib.ptr(out), _lib.ptr(pack), _lib.ptr(bfd), _lib.ptr(bod),
                                        _lib.ptr(bofd), _lib.ptr(kmd) if kmd is not None else None, B, L, d, H, 1e-5, _s()), "attn block")
@@ -371,7 +380,8 @@ def _attn_block_case(gpu_device, B, L, d, H, masked, seed):
 @pytest.mark.parametrize("B,L,d,H,masked", [(3, 128, 384, 3, False), (4, 128, 384, 3, True), (5, 100, 384, 3, True),
                                            (2, 1, 384, 3, False), (2, 128, 256, 4, False), (3, 77, 256, 2, True),
                                            (3, 128, 128, 2, False), (3, 50, 128, 4, True), (300, 128, 384, 3, True),
-                                           (4, 128, 384, 6, True), (3, 90, 384, 6, False)])
+                                           (4, 128, 384, 6, True), (3, 90, 384, 6, False),
+                                           (4, 128, 384, 8, True), (3, 70, 384, 8, False)])   # 8 heads of 48, run as 8 x 64
 def test_attn_block_fused_matches_fp32_reference(gpu_device, B, L, d, H, masked):
     assert _lib.lib().bd_attn_block_supported(d, H, L) == 1
     out, ref, xs, bo = _attn_block_case(gpu_device, B, L, d, H, masked, seed=B + L + d + H)
@@ -395,7 +405,10 @@ def test_attn_block_fused_sequences_independent_and_in_place(gpu_device):
 def test_attn_block_unsupported_shapes_are_refused(gpu_device):
     lib = _lib.lib()
     assert lib.bd_attn_block_supported(384, 3, 129) == 0
-    assert lib.bd_attn_block_supported(384, 8, 128) == 0     # head_dim 48
+    assert lib.bd_attn_block_supported(384, 12, 128) == 0    # head_dim 32 at d = 384
+    assert lib.bd_attn_block_supported(384, 4, 128) == 0     # head_dim 96
+    assert lib.bd_attn_block_width(384, 8) == 512 and lib.bd_attn_block_width(384, 3) == 384   # 8 x 48 runs as 8 x 64
+    assert lib.bd_attn_block_width(384, 4) == 0
     assert lib.bd_attn_block_supported(768, 6, 128) == 0
     a = torch.zeros(1024, device=gpu_device)
     assert lib.bd_attn_block_fused(_lib.ptr(a), _lib.ptr(a), _lib.ptr(a), _lib.ptr(a), _lib.ptr(a), _lib.ptr(a), None, 1, 200, 384, 3,
