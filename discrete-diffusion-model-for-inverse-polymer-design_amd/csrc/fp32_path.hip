@@ -95,7 +95,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args p) {
 
 constexpr int AQ = 32;           // queries per workgroup
 
-template <int DPL>               // head features per lane = dh / 8
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+template <int VEC> struct FVec { typedef f32x4 type; };
+template <> struct FVec<2> { typedef f32x2_t type; };
+
+template <int DPL>               // head features per lane = dh / 8 (even; 16-byte accesses when it divides by 4, else 8-byte)
 __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qkv, const unsigned char* __restrict__ keymask,
                                                             float* __restrict__ out, int B, int L, int H, float scale) {
   extern __shared__ float sS[];                        // [AQ][L] scores, then probabilities
@@ -105,9 +109,15 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
   const int q = min(qb * AQ + ql, L - 1);              // lanes past the sequence shadow its last query
   const size_t row0 = (size_t)b * L;
   const float* qp = qkv + (row0 + q) * 3 * d + h * dh + part * DPL;
+  constexpr int VEC = DPL % 4 == 0 ? 4 : 2;
+  typedef typename FVec<VEC>::type vec_t;
   float qv[DPL];
 #pragma unroll
-  for (int e = 0; e < DPL; e += 4) *(f32x4*)(qv + e) = *(const f32x4*)(qp + e);
+  for (int e = 0; e < DPL; e += VEC) {
+    const vec_t t = *(const vec_t*)(qp + e);
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) qv[e + c] = t[c];
+  }
   const unsigned char* km = keymask ? keymask + row0 : nullptr;
   float* srow = sS + (size_t)ql * L;
   float mx = -INFINITY;
@@ -115,9 +125,10 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
     const float* kp = qkv + (row0 + k) * 3 * d + d + h * dh + part * DPL;
     float s = 0.f;
 #pragma unroll
-    for (int e = 0; e < DPL; e += 4) {
-      const f32x4 kv = *(const f32x4*)(kp + e);
-      s += qv[e] * kv[0]; s += qv[e + 1] * kv[1]; s += qv[e + 2] * kv[2]; s += qv[e + 3] * kv[3];
+    for (int e = 0; e < DPL; e += VEC) {
+      const vec_t kv = *(const vec_t*)(kp + e);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) s += qv[e + c] * kv[c];
     }
     s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
     s = (km == nullptr || km[k]) ? s * scale : -INFINITY;
@@ -135,19 +146,21 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
     sum += pk;
     const float* vp = qkv + (row0 + k) * 3 * d + 2 * d + h * dh + part * DPL;
 #pragma unroll
-    for (int e = 0; e < DPL; e += 4) {
-      const f32x4 vv = *(const f32x4*)(vp + e);
-      o[e] += pk * vv[0]; o[e + 1] += pk * vv[1]; o[e + 2] += pk * vv[2]; o[e + 3] += pk * vv[3];
+    for (int e = 0; e < DPL; e += VEC) {
+      const vec_t vv = *(const vec_t*)(vp + e);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) o[e + c] += pk * vv[c];
     }
   }
   if (qb * AQ + ql < L) {
     const float inv = dead ? 0.f : 1.0f / sum;
     float* op = out + (row0 + q) * d + h * dh + part * DPL;
 #pragma unroll
-    for (int e = 0; e < DPL; e += 4) {
-      f32x4 v;
-      v[0] = o[e] * inv; v[1] = o[e + 1] * inv; v[2] = o[e + 2] * inv; v[3] = o[e + 3] * inv;
-      *(f32x4*)(op + e) = v;
+    for (int e = 0; e < DPL; e += VEC) {
+      vec_t v;
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) v[c] = o[e + c] * inv;
+      *(vec_t*)(op + e) = v;
     }
   }
 }
@@ -172,16 +185,20 @@ extern "C" int bd_attention_f32(const float* qkv, const unsigned char* keymask, 
                                 int dh, void* stream) {
   BD_REQUIRE(qkv && out, "bd_attention_f32: null operand");
   BD_REQUIRE(B >= 0 && L > 0 && H > 0, "bd_attention_f32: bad shape");
-  BD_REQUIRE(dh == 32 || dh == 64 || dh == 96 || dh == 128, "bd_attention_f32: head width %d unsupported (32, 64, 96, 128)", dh);
+  BD_REQUIRE(dh >= 16 && dh <= 128 && dh % 16 == 0, "bd_attention_f32: head width %d unsupported (multiples of 16 up to 128)", dh);
   BD_REQUIRE((size_t)AQ * L * 4 <= 64 * 1024, "bd_attention_f32: L=%d too long", L);
   if (B == 0) return BD_OK;
   const dim3 grid((L + AQ - 1) / AQ, H, B);
   const size_t lds = (size_t)AQ * L * 4;
   const float scale = 1.0f / sqrtf((float)dh);
   hipStream_t s = (hipStream_t)stream;
-  if (dh == 32) hipLaunchKernelGGL(attention_f32_kernel<4>, grid, dim3(256), lds, s, qkv, keymask, out, B, L, H, scale);
-  else if (dh == 64) hipLaunchKernelGGL(attention_f32_kernel<8>, grid, dim3(256), lds, s, qkv, keymask, out, B, L, H, scale);
-  else if (dh == 96) hipLaunchKernelGGL(attention_f32_kernel<12>, grid, dim3(256), lds, s, qkv, keymask, out, B, L, H, scale);
-  else hipLaunchKernelGGL(attention_f32_kernel<16>, grid, dim3(256), lds, s, qkv, keymask, out, B, L, H, scale);
+  switch (dh / 8) {
+#define BD_ATTN_F32_CASE(DPL) \
+    case DPL: hipLaunchKernelGGL(attention_f32_kernel<DPL>, grid, dim3(256), lds, s, qkv, keymask, out, B, L, H, scale); break;
+    BD_ATTN_F32_CASE(2) BD_ATTN_F32_CASE(4) BD_ATTN_F32_CASE(6) BD_ATTN_F32_CASE(8)
+    BD_ATTN_F32_CASE(10) BD_ATTN_F32_CASE(12) BD_ATTN_F32_CASE(14) BD_ATTN_F32_CASE(16)
+#undef BD_ATTN_F32_CASE
+    default: return bd_fail(BD_ERR_UNSUPPORTED, "bd_attention_f32: head width %d", dh);
+  }
   return bd_check_launch("bd_attention_f32");
 }

@@ -61,7 +61,7 @@ int bd_gemm_f32(const float* A, long long lda, const float* W, long long ldw, co
                 void* stream);
 /* out[b,l,h*dh:(h+1)*dh] = softmax(q k^T / sqrt(dh) + key padding) v in fp32; qkv rows are [q | k | v] of width
  * 3 H dh; keymask uint8 [B,L] (0 = padded key) or null; rows whose keys are all padded come out as zeros.
- * dh in {32, 64, 96, 128}, L <= 512. replaces F.scaled_dot_product_attention at src/model/backbone.py:60-66. */
+ * dh a multiple of 16 up to 128, L <= 512. replaces F.scaled_dot_product_attention at src/model/backbone.py:60-66. */
 int bd_attention_f32(const float* qkv, const unsigned char* keymask, float* out, int B, int L, int H,
                      int dh, void* stream);
 

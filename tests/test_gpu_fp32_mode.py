@@ -53,6 +53,8 @@ def test_fp32_logits_match_reference_golden(gpu_device, name):
     (384, 3, 6, 1536, 6, 128),     # the benchmark architecture
     (384, 6, 2, 1536, 3, 100),     # heads of 64, ragged tile edges (M = 300)
     (768, 8, 2, 3072, 2, 77),      # heads of 96
+    (384, 8, 2, 1536, 3, 90),      # the reference's default block: heads of 48 (8-byte accesses per lane)
+    (256, 16, 1, 1024, 2, 40),     # heads of 16
     (1024, 8, 2, 4096, 2, 512),    # stress shape: d = 1024, L = 512
 ])
 def test_fp32_logits_match_oracle(gpu_device, hidden, heads, layers, ffn, B, L):
