@@ -76,7 +76,7 @@ class StepArgs(C.Structure):
         ("n_counted", C.c_int), ("n_bond", C.c_int), ("n_ns", C.c_int), ("R", C.c_int),
         ("B", C.c_int), ("L", C.c_int), ("V", C.c_int), ("d", C.c_int),
         ("mask_id", C.c_int), ("pad_id", C.c_int), ("bos_id", C.c_int), ("eos_id", C.c_int),
-        ("open_id", C.c_int), ("close_id", C.c_int), ("boost_id", C.c_int),
+        ("open_id", C.c_int), ("close_id", C.c_int), ("boost_id", C.c_int), ("count_id", C.c_int),
         ("variant", C.c_int), ("use_constraints", C.c_int), ("t", C.c_int),
         ("temperature", C.c_float),
         ("seed", C.c_ulonglong),

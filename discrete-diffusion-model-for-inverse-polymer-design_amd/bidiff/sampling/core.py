@@ -16,6 +16,7 @@ from .. import _lib
 
 TF_BOND, TF_RING, TF_OPEN, TF_CLOSE, TF_SPECIAL, TF_COUNTED, TF_EOS = 1, 2, 4, 8, 16, 32, 64
 VB_FIXED, VB_SYNTAX, VB_URGENCY, VB_SORTED, VB_NATURAL_EOS = 1, 2, 4, 8, 16
+VB_DYN_ALL_MASKS, VB_DYN_SINGLE, VB_SPECIAL_UNFIXED = 32, 64, 128
 
 
 def unmask_count_table(num_steps: int, max_len: int) -> np.ndarray:
@@ -102,7 +103,7 @@ def fill_step_args(a: _lib.StepArgs, tt: TokenTables, dt: DeviceTables):
     a.n_counted, a.n_bond, a.n_ns, a.R = len(tt.counted_ids), len(tt.bond_ids), len(tt.non_special), len(tt.ring_ids)
     a.V = tt.V
     a.mask_id, a.pad_id, a.bos_id, a.eos_id = tt.mask_id, tt.pad_id, tt.bos_id, tt.eos_id
-    a.open_id, a.close_id, a.boost_id = tt.open_id, tt.close_id, tt.boost_id
+    a.open_id, a.close_id, a.boost_id, a.count_id = tt.open_id, tt.close_id, tt.boost_id, tt.count_id
 
 
 class ReverseSampler:
@@ -132,9 +133,10 @@ class ReverseSampler:
         return self._ktab[L]
 
     def run(self, ids, attention_mask, fixed_mask=None, natural_eos=False, seq_offset=0,
-            progress=None, has_eos=None):
+            progress=None, has_eos=None, variant_extra=0):
         """Mutates ``ids`` (and, in natural-EOS mode, ``attention_mask``) in place; returns the
-        final ids after the post-loop repairs."""
+        final ids after the post-loop repairs. ``variant_extra``: VB_* bits OR-ed into the sampler's
+        variant for this call (the sample_conditional flavours of the SELFIES samplers)."""
         tt, dt = self.tt, self._tables()
         backbone = self.model.backbone
         self.model.eval()
@@ -149,7 +151,7 @@ class ReverseSampler:
         attn = attention_mask.to(torch.long).contiguous()
         keymask = (attn != 0).to(torch.uint8).contiguous()
         fixed = None if fixed_mask is None else fixed_mask.to(torch.uint8).contiguous()
-        variant = tt.variant | (VB_NATURAL_EOS if natural_eos else 0)
+        variant = tt.variant | (VB_NATURAL_EOS if natural_eos else 0) | int(variant_extra)
         if natural_eos and has_eos is None:
             has_eos = torch.zeros(B, dtype=torch.uint8, device=dev)
         seed = self.seed
@@ -219,6 +221,7 @@ class ReverseSampler:
                     "raw_logits": (raw if full else dump).cpu().clone(),
                     "ids_after": ids.cpu().clone(), "seed": seed, "seq_offset": int(seq_offset),
                     "logits_after": logits.cpu().clone() if full else None,
+                    "variant_extra": int(variant_extra), "fixed": None if fixed is None else fixed.cpu().clone(),
                 })
 
         # post-loop repairs

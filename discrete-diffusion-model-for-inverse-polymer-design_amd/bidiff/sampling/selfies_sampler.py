@@ -118,3 +118,39 @@ class ConstrainedSampler:
             all_ids.append(ids)
             all_strings.extend(s)
         return all_ids, all_strings
+
+    def sample_conditional(self, batch_size: int, seq_length: int,
+                           prefix_ids: Optional[torch.Tensor] = None,
+                           suffix_ids: Optional[torch.Tensor] = None, show_progress: bool = True,
+                           allow_natural_eos: bool = False, seq_offset: int = 0) -> Tuple[torch.Tensor, List[str]]:
+        """Prefix after BOS and suffix before the final EOS stay fixed; a suffix forces the fixed-EOS
+        mode (reference SELFIES sampler.py:553-737). Positions are chosen among the non-fixed masks,
+        the special-token forbids apply to those positions only (:639-664) and the in-step
+        placeholder update edits every remaining MASK (:703-710)."""
+        self.diffusion_model.eval()
+        natural = bool(allow_natural_eos) and suffix_ids is None
+        ids = torch.full((batch_size, seq_length), self.mask_id, dtype=torch.long, device=self.device)
+        ids[:, 0] = self.bos_id
+        has_eos = torch.zeros(batch_size, dtype=torch.uint8, device=self.device)
+        fixed = torch.zeros_like(ids, dtype=torch.bool)
+        fixed[:, 0] = True
+        if not natural:
+            ids[:, -1] = self.eos_id
+            fixed[:, -1] = True
+            has_eos[:] = 1
+        if prefix_ids is not None:
+            n = prefix_ids.shape[1]
+            ids[:, 1:1 + n] = prefix_ids.to(self.device)
+            fixed[:, 1:1 + n] = True
+        if suffix_ids is not None:
+            n = suffix_ids.shape[1]
+            ids[:, -1 - n:-1] = suffix_ids.to(self.device)
+            fixed[:, -1 - n:-1] = True
+        self._core.num_steps = int(self.num_steps)
+        self._core.temperature = float(self.temperature)
+        self._core.use_constraints = bool(self.use_constraints)
+        extra = core.VB_FIXED | core.VB_DYN_ALL_MASKS | core.VB_SPECIAL_UNFIXED
+        ids = self._core.run(ids, torch.ones_like(ids), fixed, natural_eos=natural, seq_offset=seq_offset,
+                             progress=_progress(show_progress, "Sampling"), has_eos=has_eos, variant_extra=extra)
+        strings = self.tokenizer.batch_decode(ids.cpu().tolist(), skip_special_tokens=True)
+        return ids, strings

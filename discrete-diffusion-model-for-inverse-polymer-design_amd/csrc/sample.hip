@@ -81,11 +81,14 @@ __device__ __forceinline__ void wave_argmax(float& best, int& idx) {
 
 // Is token v (class bits tf) forbidden at masked position l?
 __device__ __forceinline__ bool forbidden_at(const bd_step_args& p, const Smem& s, int l, int v, int tf,
-                                             bool cnt_forbid, bool eos_forbid) {
-  if (tf & BD_TF_SPECIAL) return true;
-  if ((tf & BD_TF_EOS) && eos_forbid) return true;
+                                             bool cnt_forbid, bool eos_forbid, bool single_forbid) {
+  // the specials: everywhere a MASK stands, or (SELFIES sample_conditional) at the non-fixed ones only
+  const bool sp = !(p.variant & BD_VB_SPECIAL_UNFIXED) || !(s.pf[l] & PF_FIXED);
+  if (sp && (tf & BD_TF_SPECIAL)) return true;
+  if (sp && (tf & BD_TF_EOS) && eos_forbid) return true;
   if (!p.use_constraints) return false;
   if (cnt_forbid && (tf & BD_TF_COUNTED)) return true;
+  if (single_forbid && v == p.count_id) return true;
   if (p.variant & BD_VB_SYNTAX) {
     const int f = s.pf[l];
     if ((tf & BD_TF_CLOSE) && (f & (PF_CLOSE | PF_DYN_CLOSE))) return true;
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(64) void sample_step_kernel(bd_step_args p) {
   n_sel = bd_wave_sum_i(n_sel);
   total = bd_wave_sum_i(total);
   bool cnt_forbid = cons && total >= 2;
+  bool single_forbid = false;  // BD_VB_DYN_SINGLE: the direct placeholder id alone got forbidden in this step
   const bool natural = (p.variant & BD_VB_NATURAL_EOS) != 0;
   bool eos_forbid = true;  // EOS is an ordinary forbidden special unless natural-EOS mode
   if (natural) eos_forbid = p.has_eos[b] != 0;
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(64) void sample_step_kernel(bd_step_args p) {
     for (int i = lane; i < tot; i += 64) {
       const int l = i / V, v = i - l * V;
       float x = lg[i] / p.temperature;
-      if ((s.pf[l] & PF_MASK0) && forbidden_at(p, s, l, v, p.tok_flags[v], cnt_forbid, eos_forbid))
+      if ((s.pf[l] & PF_MASK0) && forbidden_at(p, s, l, v, p.tok_flags[v], cnt_forbid, eos_forbid, false))
         x = -INFINITY;
       lg[i] = x;
     }
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(64) void sample_step_kernel(bd_step_args p) {
         if (lg) lg[(size_t)pos * V + v] = acc;  // raw dump for replay
         x = acc / p.temperature;
         if ((pflag & PF_BOOST) && v == p.boost_id) x = 100.0f;
-        if (forbidden_at(p, s, pos, v, p.tok_flags[v], cnt_forbid, eos_forbid)) x = -INFINITY;
+        if (forbidden_at(p, s, pos, v, p.tok_flags[v], cnt_forbid, eos_forbid, single_forbid)) x = -INFINITY;
       }
       if (x > -INFINITY) {
         const float u = p.u_tok ? p.u_tok[((size_t)b * L + pos) * V + v]
@@ -427,7 +431,23 @@ __global__ __launch_bounds__(64) void sample_step_kernel(bd_step_args p) {
 
     if (cons) {
       const int tf = p.tok_flags[tok];
-      if (tf & BD_TF_COUNTED) {
+      if ((p.variant & BD_VB_DYN_SINGLE) && (tf & BD_TF_COUNTED)) {
+        // Group_SELFIES sample_conditional: only the direct placeholder id counts and gets forbidden
+        if (tok == p.count_id) {
+          int c = 0;
+          for (int j = 0; j < CH; ++j) {
+            const int l = l0 + j;
+            if (l < L && s.ids[l] == p.count_id) c++;
+          }
+          c = bd_wave_sum_i(c);
+          if (c >= 2) {
+            single_forbid = true;
+            if (logits_mode)
+              for (int l = lane; l < L; l += 64)
+                if (s.ids[l] == p.mask_id) lg[(size_t)l * V + p.count_id] = -INFINITY;
+          }
+        }
+      } else if (tf & BD_TF_COUNTED) {
         int tot2 = 0;
         for (int j = 0; j < CH; ++j) {
           const int l = l0 + j;
@@ -437,8 +457,9 @@ __global__ __launch_bounds__(64) void sample_step_kernel(bd_step_args p) {
         if (tot2 >= 2) {
           cnt_forbid = true;
           if (logits_mode) {
+            const bool all_masks = (p.variant & BD_VB_DYN_ALL_MASKS) != 0;
             for (int l = lane; l < L; l += 64) {
-              if (s.ids[l] == p.mask_id && !(s.pf[l] & PF_FIXED))
+              if (s.ids[l] == p.mask_id && (all_masks || !(s.pf[l] & PF_FIXED)))
                 for (int q = 0; q < p.n_counted; ++q) lg[(size_t)l * V + p.counted_ids[q]] = -INFINITY;
             }
           }
@@ -669,6 +690,8 @@ extern "C" int bd_sample_step(const bd_step_args* a, void* stream) {
     BD_REQUIRE(p.has_eos != nullptr, "bd_sample_step: natural-EOS mode needs has_eos");
   if (p.variant & BD_VB_URGENCY)
     BD_REQUIRE(p.boost_id >= 0 && p.boost_id < p.V, "bd_sample_step: bad boost id");
+  if (p.variant & BD_VB_DYN_SINGLE)
+    BD_REQUIRE(p.count_id >= 0 && p.count_id < p.V, "bd_sample_step: bad count id");
   if (p.B == 0) return BD_OK;
   const size_t lds = smem_bytes(p.L, p.V, p.d, p.R > 0 ? p.R : 1);
   BD_REQUIRE(lds <= 64 * 1024, "bd_sample_step: working set of %zu bytes per sequence exceeds LDS", lds);

@@ -417,6 +417,14 @@ int bd_cast_f32_to_bf16(const float* x, void* y, long long n, void* stream);
 #define BD_VB_URGENCY 4      /* SELFIES placeholder urgency boost                          */
 #define BD_VB_SORTED 8       /* draw the chosen positions left to right (SELFIES)          */
 #define BD_VB_NATURAL_EOS 16 /* SELFIES allow_natural_eos=True                              */
+/* sample_conditional of the SELFIES / Group_SELFIES samplers (positions are chosen among the non-fixed masks
+ * like SMILES, but the in-step edits differ from their sample()):                                         */
+#define BD_VB_DYN_ALL_MASKS 32   /* the in-step counted-token update edits every MASK position, fixed or
+                                    not (Bi_Diffusion_SELFIES sampler.py:708-709, Group :685-686)          */
+#define BD_VB_DYN_SINGLE 64      /* that update is triggered by count_id alone, counts count_id alone and
+                                    forbids count_id alone (Group sampler.py:679-687)                      */
+#define BD_VB_SPECIAL_UNFIXED 128 /* special / EOS columns are forbidden at non-fixed MASK positions only
+                                    (Bi_Diffusion_SELFIES sampler.py:639-664)                              */
 
 typedef struct bd_step_args {
   long long* ids;               /* [B,L] in/out                                             */
@@ -440,6 +448,7 @@ typedef struct bd_step_args {
   int n_counted, n_bond, n_ns, R;
   int B, L, V, d;
   int mask_id, pad_id, bos_id, eos_id, open_id, close_id, boost_id;
+  int count_id;                 /* the direct star / placeholder id (BD_VB_DYN_SINGLE), else unused  */
   int variant, use_constraints, t;
   float temperature;
   unsigned long long seed;

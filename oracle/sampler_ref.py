@@ -24,7 +24,7 @@ class StepArgs(C.Structure):
         ("n_counted", C.c_int), ("n_bond", C.c_int), ("n_ns", C.c_int), ("R", C.c_int),
         ("B", C.c_int), ("L", C.c_int), ("V", C.c_int), ("d", C.c_int),
         ("mask_id", C.c_int), ("pad_id", C.c_int), ("bos_id", C.c_int), ("eos_id", C.c_int),
-        ("open_id", C.c_int), ("close_id", C.c_int), ("boost_id", C.c_int),
+        ("open_id", C.c_int), ("close_id", C.c_int), ("boost_id", C.c_int), ("count_id", C.c_int),
         ("variant", C.c_int), ("use_constraints", C.c_int), ("t", C.c_int),
         ("temperature", C.c_float),
         ("seed", C.c_ulonglong),
@@ -161,8 +161,10 @@ class Tables:
 
 
 def sample_step(tb, ids, logits, ktable_row, t, temperature=1.0, use_constraints=True, fixed=None,
-                u_sel=None, u_tok=None, seed=0, seq_offset=0, natural_eos=False, attn=None, has_eos=None):
-    """One reverse step on copies; returns dict(ids, logits[, attn, has_eos])."""
+                u_sel=None, u_tok=None, seed=0, seq_offset=0, natural_eos=False, attn=None, has_eos=None,
+                variant_extra=0):
+    """One reverse step on copies; returns dict(ids, logits[, attn, has_eos]). ``variant_extra``: the
+    sample_conditional bits (1 fixed, 32 / 64 / 128) OR-ed into the sampler's variant."""
     ids = np.array(ids, dtype=np.int64, order="C", copy=True)
     B, L = ids.shape
     logits = np.array(logits, dtype=np.float32, order="C", copy=True)
@@ -190,8 +192,8 @@ def sample_step(tb, ids, logits, ktable_row, t, temperature=1.0, use_constraints
     a.n_counted, a.n_bond, a.n_ns, a.R = len(tb.counted_list), len(tb.bond_ids_list), len(tb.non_special_list), len(tb.ring_ids_list)
     a.B, a.L, a.V, a.d = B, L, V, 0
     a.mask_id, a.pad_id, a.bos_id, a.eos_id = tb.mask_id, tb.pad_id, tb.bos_id, tb.eos_id
-    a.open_id, a.close_id, a.boost_id = tb.open_id, tb.close_id, tb.boost_id
-    a.variant = tb.variant | (16 if natural_eos else 0)
+    a.open_id, a.close_id, a.boost_id, a.count_id = tb.open_id, tb.close_id, tb.boost_id, tb.count_id
+    a.variant = tb.variant | (16 if natural_eos else 0) | int(variant_extra)
     a.use_constraints, a.t = int(use_constraints), int(t)
     a.temperature = float(temperature)
     a.seed, a.seq_offset = int(seed), int(seq_offset)

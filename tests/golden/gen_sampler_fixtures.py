@@ -144,9 +144,13 @@ def run_case(variant, Sampler, tok, case):
         elif kind == "lengths":
             ids, strings = smp.sample_with_lengths(case["lengths"], max_length=L, show_progress=False)
         elif kind == "conditional":
+            kw = {}
+            if variant == "selfies":
+                kw["allow_natural_eos"] = bool(case.get("natural_eos", False))
+            pre, suf = case.get("prefix"), case.get("suffix")
             ids, strings = smp.sample_conditional(
-                B, L, prefix_ids=torch.tensor(case["prefix"]).repeat(B, 1),
-                suffix_ids=torch.tensor(case["suffix"]).repeat(B, 1), show_progress=False)
+                B, L, prefix_ids=None if not pre else torch.tensor(pre).repeat(B, 1),
+                suffix_ids=None if not suf else torch.tensor(suf).repeat(B, 1), show_progress=False, **kw)
         else:
             raise ValueError(kind)
     out = {

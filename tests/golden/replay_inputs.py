@@ -53,6 +53,18 @@ CASES = {
                     scale=2.0, bias={_SF["[I+3]"]: 2.0}),
         "long70": dict(kind="sample", B=3, L=70, T=5, temperature=1.0, use_constraints=True, seed=205,
                        scale=2.0, bias={_SF["[I+3]"]: -2.0}),
+        # sample_conditional: prefix / suffix fixed, positions chosen among the non-fixed masks
+        "conditional": dict(kind="conditional", B=6, L=18, T=7, temperature=1.0, use_constraints=True, seed=206,
+                            scale=2.0, bias={_SF["[I+3]"]: 2.5}, prefix=[_SF["[C]"], _SF["[I+3]"]],
+                            suffix=[_SF["[=O]"]]),
+        # a MASK inside the fixed prefix: it is never drawn, but it counts as masked in the constraint, keeps
+        # its special-token logits and is edited by the in-step placeholder update
+        "conditional_maskfix": dict(kind="conditional", B=6, L=16, T=6, temperature=0.9, use_constraints=True,
+                                    seed=207, scale=2.0, bias={_SF["[I+3]"]: 3.0},
+                                    prefix=[_SF["[C]"], _SF["[MASK]"], _SF["[N]"]], suffix=[_SF["[MASK]"], _SF["[O]"]]),
+        "conditional_natural": dict(kind="conditional", B=8, L=20, T=8, temperature=1.1, use_constraints=True,
+                                    seed=208, scale=2.0, bias={_SF["[I+3]"]: 0.5, _SF["[EOS]"]: 2.5},
+                                    prefix=[_SF["[C]"]], suffix=None, natural_eos=True),
     },
     "group": {
         "on_small": dict(kind="sample", B=8, L=20, T=10, temperature=1.0, use_constraints=True, seed=301,
@@ -62,8 +74,33 @@ CASES = {
                     scale=2.0, bias={_GR["[IH0+3]"]: 3.0, _GR["[:/0G4]"]: 3.0}),
         "long70": dict(kind="sample", B=3, L=70, T=5, temperature=1.0, use_constraints=True, seed=303,
                        scale=2.0, bias={_GR["[IH0+3]"]: 2.0, _GR["[:/0G1]"]: 2.0}),
+        # sample_conditional: the in-step update looks at the direct placeholder id alone
+        "conditional": dict(kind="conditional", B=8, L=18, T=7, temperature=1.0, use_constraints=True, seed=304,
+                            scale=2.0, bias={_GR["[IH0+3]"]: 4.0, _GR["[:/0G0]"]: 3.5, _GR["[:/0G4]"]: 3.0},
+                            prefix=[_GR["[C]"]], suffix=[_GR["[O]"]]),
+        "conditional_maskfix": dict(kind="conditional", B=8, L=16, T=5, temperature=1.0, use_constraints=True,
+                                    seed=305, scale=2.0, bias={_GR["[IH0+3]"]: 4.5, _GR["[:/0G1]"]: 3.5},
+                                    prefix=[_GR["[C]"], _GR["[MASK]"]], suffix=[_GR["[MASK]"], _GR["[O]"]]),
     },
 }
+
+
+# variant bits of the step kernel / oracle that the sample_conditional flavours add (include/bidiff.h)
+CONDITIONAL_EXTRA = {"smiles": 0, "selfies": 1 | 32 | 128, "group": 1 | 32 | 64}
+
+
+def conditional_fixed(case, natural=False):
+    """fixed_mask of a sample_conditional case: BOS, the prefix, the suffix and (unless EOS is sampled) EOS."""
+    B, L = case["B"], case["L"]
+    fixed = np.zeros((B, L), dtype=np.uint8)
+    fixed[:, 0] = 1
+    if not natural:
+        fixed[:, -1] = 1
+    if case.get("prefix"):
+        fixed[:, 1:1 + len(case["prefix"])] = 1
+    if case.get("suffix"):
+        fixed[:, -1 - len(case["suffix"]):-1] = 1
+    return fixed
 
 
 def step_logits(case, t, B, L, V):

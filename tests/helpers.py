@@ -67,6 +67,16 @@ def load_cases(variant):
     return out
 
 
+def case_fixed_and_variant(variant, case, ids0, mask_id):
+    """(fixed_mask bytes or None, extra variant bits) of a golden case from its initial ids."""
+    if case["kind"] == "conditional":
+        natural = bool(case.get("natural_eos", False))
+        return RI.conditional_fixed(case, natural), RI.CONDITIONAL_EXTRA["smiles" if variant == "bpe" else variant]
+    if variant in ("smiles", "bpe"):
+        return (ids0 != mask_id).astype(np.uint8), 0
+    return None, 0
+
+
 def oracle_replay(variant, case, golden):
     """Run the oracle over the whole T-step loop of a golden case.
     Returns (list of ids after each step, final ids, edited last-step logits)."""
@@ -77,8 +87,8 @@ def oracle_replay(variant, case, golden):
     ktab = core.unmask_count_table(T, L)
     ids = golden["ids_before"][0].copy()
     attn = golden["attn_before"][0].copy()
-    fixed = (ids != tb.mask_id).astype(np.uint8) if variant in ("smiles", "bpe") else None
     natural = bool(case.get("natural_eos", False))
+    fixed, extra = case_fixed_and_variant(variant, case, ids, tb.mask_id)
     has_eos = None
     if variant == "selfies":
         has_eos = np.zeros(B, dtype=np.uint8) if natural else np.ones(B, dtype=np.uint8)
@@ -88,7 +98,7 @@ def oracle_replay(variant, case, golden):
                               temperature=case["temperature"], use_constraints=case["use_constraints"],
                               fixed=fixed, u_sel=RI.step_u_sel(case, t, B, L), u_tok=RI.step_u_tok(case, t, B, L, V),
                               natural_eos=natural, attn=attn if natural else None,
-                              has_eos=has_eos if natural else None)
+                              has_eos=has_eos if natural else None, variant_extra=extra)
         ids = res["ids"]
         if natural:
             attn, has_eos = res["attn"], res["has_eos"]
@@ -111,7 +121,7 @@ def hip_tables(tb, device):
 
 def hip_step(tb, dt, ids, ktable_row, t, logits=None, hidden=None, wout=None, dump=None, temperature=1.0,
              use_constraints=True, fixed=None, u_sel=None, u_tok=None, seed=0, seq_offset=0, natural_eos=False,
-             attn=None, keymask=None, has_eos=None):
+             attn=None, keymask=None, has_eos=None, variant_extra=0):
     """Call bd_sample_step on device tensors (mutated in place)."""
     import ctypes as C
     import torch
@@ -138,8 +148,8 @@ def hip_step(tb, dt, ids, ktable_row, t, logits=None, hidden=None, wout=None, du
     a.n_counted, a.n_bond, a.n_ns, a.R = len(tb.counted_list), len(tb.bond_ids_list), len(tb.non_special_list), len(tb.ring_ids_list)
     a.B, a.L, a.V = B, L, tb.V
     a.mask_id, a.pad_id, a.bos_id, a.eos_id = tb.mask_id, tb.pad_id, tb.bos_id, tb.eos_id
-    a.open_id, a.close_id, a.boost_id = tb.open_id, tb.close_id, tb.boost_id
-    a.variant = tb.variant | (16 if natural_eos else 0)
+    a.open_id, a.close_id, a.boost_id, a.count_id = tb.open_id, tb.close_id, tb.boost_id, tb.count_id
+    a.variant = tb.variant | (16 if natural_eos else 0) | int(variant_extra)
     a.use_constraints, a.t = int(use_constraints), int(t)
     a.temperature = float(temperature)
     a.seed, a.seq_offset = int(seed), int(seq_offset)

@@ -35,7 +35,8 @@ def test_hip_step_replays_reference_golden(gpu_device, variant, name):
     ids = torch.from_numpy(golden["ids_before"][0].copy()).to(dev)
     attn = torch.from_numpy(golden["attn_before"][0].copy()).to(dev)
     keymask = (attn != 0).to(torch.uint8)
-    fixed = (ids != tb.mask_id).to(torch.uint8) if variant == "smiles" else None
+    fixed_np, extra = H.case_fixed_and_variant(variant, case, golden["ids_before"][0], tb.mask_id)
+    fixed = None if fixed_np is None else torch.from_numpy(fixed_np).to(dev)
     natural = bool(case.get("natural_eos", False))
     has_eos = None
     if variant == "selfies":
@@ -48,7 +49,7 @@ def test_hip_step_replays_reference_golden(gpu_device, variant, name):
                    u_sel=torch.from_numpy(RI.step_u_sel(case, t, B, L)).to(dev),
                    u_tok=torch.from_numpy(RI.step_u_tok(case, t, B, L, V)).to(dev),
                    natural_eos=natural, attn=attn if natural else None, keymask=keymask if natural else None,
-                   has_eos=has_eos if natural else None)
+                   has_eos=has_eos if natural else None, variant_extra=extra)
         if i + 1 < T:
             np.testing.assert_array_equal(ids.cpu().numpy(), golden["ids_before"][i + 1], err_msg=f"after t={t}")
             np.testing.assert_array_equal(attn.cpu().numpy(), golden["attn_before"][i + 1])

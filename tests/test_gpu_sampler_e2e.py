@@ -24,7 +24,7 @@ def build_model(tok, device, T, heads=2, layers=2, d=128, F=256):
                                     bos_token_id=tok.bos_token_id, eos_token_id=tok.eos_token_id).to(device).eval()
 
 
-def replay(records, tb, T, L, temperature, use_constraints, fixed, natural=False):
+def replay(records, tb, T, L, temperature, use_constraints, fixed, natural=False, extra=0):
     ktab = core.unmask_count_table(T, L)
     last = None
     for r in records:
@@ -33,7 +33,7 @@ def replay(records, tb, T, L, temperature, use_constraints, fixed, natural=False
         o = ora.sample_step(tb, r["ids_before"].numpy(), r["raw_logits"].numpy(), ktab[t], t, temperature=temperature,
                             use_constraints=use_constraints, fixed=fixed, seed=r["seed"], seq_offset=r["seq_offset"],
                             natural_eos=natural, attn=r["attn_before"].numpy() if natural else None,
-                            has_eos=has_eos if (natural or has_eos is not None) else None)
+                            has_eos=has_eos if (natural or has_eos is not None) else None, variant_extra=extra)
         np.testing.assert_array_equal(o["ids"], r["ids_after"].numpy(), err_msg=f"step t={t} ({r['mode']})")
         last = (o, r)
     return last
@@ -74,20 +74,88 @@ def test_sampler_end_to_end_replayed_by_oracle(gpu_device, variant, kw):
         assert ((out == cid).sum(1) == 2).all(), "exactly two stars / placeholders after the repairs"
 
 
-def test_sampling_is_independent_of_batch_split(gpu_device):
-    """Sequences are independent units keyed by their global index: one batch of 32 equals two
-    batches of 16 with offsets 0 and 16 (what a multi-process shard does)."""
-    T, L = 8, 32
-    smp0, tok = H.make_sampler("smiles")
+@pytest.mark.parametrize("variant,natural,maskfix", [("smiles", False, False), ("selfies", False, False),
+                                                     ("selfies", True, False), ("selfies", False, True),
+                                                     ("group", False, False), ("group", False, True)])
+def test_sample_conditional_replayed_by_oracle(gpu_device, variant, natural, maskfix):
+    """sample_conditional of the three sampler classes (SMILES sampler.py:913-960, SELFIES :553-737,
+    Group :593-696): prefix / suffix stay, every step replays bit-exactly through the oracle with the
+    flavour's variant bits, and the repaired ids match."""
+    T, B, L = 12, 16, 36
+    smp0, tok = H.make_sampler(variant)
     model = build_model(tok, gpu_device, T)
+    smp, _ = H.make_sampler(variant, model=model, num_steps=T, temperature=1.1, use_constraints=True,
+                            device=str(gpu_device))
+    smp._core.seed = 99
+    smp._core.record = []
+    tb = H.oracle_tables(smp)
+    v = tok.vocab
+    counted = {"smiles": "*", "selfies": "[I+3]", "group": "[IH0+3]"}[variant]
+    plain = {"smiles": "C", "selfies": "[C]", "group": "[C]"}[variant]
+    pre = [v[plain], v[counted]] + ([v["[MASK]"]] if maskfix else [])
+    suf = None if natural else ([v["[MASK]"], v[plain]] if maskfix else [v[plain]])
+    kw = {"allow_natural_eos": True} if natural else {}
+    ids, strings = smp.sample_conditional(
+        B, L, prefix_ids=torch.tensor(pre).repeat(B, 1),
+        suffix_ids=None if suf is None else torch.tensor(suf).repeat(B, 1), show_progress=False, **kw)
+    rec = smp._core.record
+    assert len(rec) == T
+    fixed = rec[0]["fixed"].numpy()
+    extra = rec[0]["variant_extra"]
+    assert extra == RI.CONDITIONAL_EXTRA[variant]
+    o, r = replay(rec, tb, T, L, 1.1, True, fixed, natural, extra)
+    of = ora.sample_fixup(tb, o["ids"], o["logits"], natural_eos=natural, attn=o["attn"], has_eos=o["has_eos"])
+    out = ids.cpu().numpy()
+    np.testing.assert_array_equal(out, of["ids"])
+    # what was fixed stays unless a post-loop repair rewrote it (the reference's repairs ignore fixed_mask)
+    before_fix = rec[-1]["ids_after"].numpy()
+    start = rec[0]["ids_before"].numpy()
+    assert (before_fix[fixed != 0] == start[fixed != 0]).all()
+    assert (before_fix[fixed == 0] != tok.mask_token_id).all()
+    assert len(strings) == B
+
+
+@pytest.mark.parametrize("variant,natural", [("smiles", False), ("selfies", False), ("selfies", True), ("group", False)])
+def test_sampling_is_independent_of_batch_split(gpu_device, variant, natural):
+    """Sequences are independent units keyed by their global index: one batch of 32 equals two
+    batches of 16 with offsets 0 and 16 (what a multi-process shard does), for every sampler class
+    and with sampled EOS."""
+    T, L = 8, 32
+    smp0, tok = H.make_sampler(variant)
+    model = build_model(tok, gpu_device, T)
+    kw = {"allow_natural_eos": True} if natural else {}
     outs = []
     for split in (1, 2):
-        smp, _ = H.make_sampler("smiles", model=model, num_steps=T, device=str(gpu_device))
+        smp, _ = H.make_sampler(variant, model=model, num_steps=T, device=str(gpu_device))
         smp._core.seed = 77
         n = 32 // split
-        parts = [smp.sample(n, L, show_progress=False, seq_offset=i * n)[0] for i in range(split)]
+        parts = [smp.sample(n, L, show_progress=False, seq_offset=i * n, **kw)[0] for i in range(split)]
         outs.append(torch.cat(parts).cpu())
     assert torch.equal(outs[0], outs[1])
+
+
+def test_group_variable_length_and_rejection(gpu_device):
+    """Group sampler methods the reference's step2 script calls (sample_variable_length, Group sampler.py:466-513)
+    and the rejection wrapper (:515-591) with the validity callback on the host."""
+    T = 6
+    smp0, tok = H.make_sampler("group")
+    model = build_model(tok, gpu_device, T)
+    smp, _ = H.make_sampler("group", model=model, num_steps=T, device=str(gpu_device))
+    np.random.seed(5)
+    all_ids, strings = smp.sample_variable_length(20, length_range=(10, 30), batch_size=64, samples_per_length=8,
+                                                  show_progress=False)
+    assert len(strings) == 20 and [x.shape[0] for x in all_ids] == [8, 8, 4]
+    assert all(10 <= x.shape[1] <= 30 for x in all_ids)
+    assert all((x != tok.mask_token_id).all() for x in all_ids)
+    smp.count_stars_fn = lambda s: s.count("[IH0+3]")
+    smp.check_validity_fn = lambda s: True
+    none, good = smp.sample_with_rejection(10, 24, batch_size=16, max_attempts=4, show_progress=False)
+    assert none == [] and len(good) <= 10 and all(g.count("[IH0+3]") == 2 for g in good)
+    smp.check_validity_fn = None
+    import sys
+    if "src.utils.chemistry" not in sys.modules:
+        with pytest.raises(RuntimeError, match="validity"):
+            smp.sample_with_rejection(2, 24, batch_size=4, max_attempts=1, show_progress=False)
 
 
 def test_full_batch_invariants(gpu_device):

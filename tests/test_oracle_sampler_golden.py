@@ -42,5 +42,9 @@ def test_no_mask_left_and_two_stars():
         for name, (case, golden) in H.load_cases(variant).items():
             smp, tok = H.make_sampler(variant)
             ids = golden["final_ids"]
+            if name.endswith("maskfix"):      # MASK tokens inside the fixed prefix / suffix stay
+                fixed = RI.conditional_fixed(case).astype(bool)
+                assert (ids[~fixed] != tok.mask_token_id).all(), (variant, name)
+                continue
             assert (ids != tok.mask_token_id).all(), (variant, name)
             assert (ids[:, 0] == tok.bos_token_id).all()
