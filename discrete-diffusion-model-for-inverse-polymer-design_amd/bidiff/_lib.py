@@ -107,13 +107,13 @@ SIGNATURES = {
     "bd_dropout_f32_to_bf16": (C.c_int, [VP, VP, C.c_int, C.c_int, VP, C.c_uint, VP]),
     "bd_collate_batch": (C.c_int, [VP, VP, VP, C.c_longlong, C.c_int, C.c_int, C.c_int, VP, VP, VP, VP]),
     "bd_pool_hidden": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
-    "bd_embed_drop": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP, C.c_uint, VP]),
+    "bd_embed_drop": (C.c_int, [VP, VP, VP, VP, VP, VP] + [C.c_int] * 6 + [VP, C.c_uint, VP]),
     "bd_gemm_bf16_drop": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     VP, C.c_uint, VP]),
     "bd_attention_fwd_drop": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, C.c_uint, VP]),
     "bd_attention_bwd_drop": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP,
                                         C.c_uint, VP]),
-    "bd_embed": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP]),
+    "bd_embed": (C.c_int, [VP, VP, VP, VP, VP, VP] + [C.c_int] * 6 + [VP]),
     "bd_layernorm": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_float, VP]),
     "bd_gemm_f32": (C.c_int, [VP, C.c_longlong, VP, C.c_longlong, VP, VP, VP, C.c_longlong, C.c_int, C.c_int, C.c_int,
                               C.c_int, VP]),
@@ -133,7 +133,7 @@ SIGNATURES = {
                                C.c_int, C.c_int, VP, C.c_float, VP]),
     "bd_colsum_bf16": (C.c_int, [VP, C.c_int, VP, C.c_int, C.c_int, VP]),
     "bd_attention_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
-    "bd_embed_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
+    "bd_embed_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP] + [C.c_int] * 7 + [VP]),
     "bd_sumsq_f32": (C.c_int, [VP, C.c_longlong, VP, VP]),
     "bd_adamw_step": (C.c_int, [VP, VP, VP, VP, C.c_longlong] + [C.c_float] * 7 + [VP, C.c_float, VP]),
     "bd_multi_cast_bf16": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP]),

@@ -18,7 +18,11 @@ class DeviceBatchLoader:
         self.pad_to_max_length = bool(pad_to_max_length)
         self._tok, self._off = store.to_device(self.device)
         self._err = torch.zeros(1, dtype=torch.int32, device=self.device)
-        self._pinned = None
+        # ring of pinned index buffers, each with the event of its last upload: a buffer is rewritten only
+        # after the copy that read it has finished, so the host may run any number of batches ahead
+        self._ring = []
+        self._ring_pos = 0
+        self.ring_slots = 4
 
     def __len__(self):
         return len(self.batch_sampler)
@@ -36,10 +40,7 @@ class DeviceBatchLoader:
         if idx.min() < 0 or idx.max() >= len(self.store):
             raise IndexError("DeviceBatchLoader: sample index out of range")
         L = self.store.max_length if self.pad_to_max_length else int(self.store.lengths[idx].max())
-        if self._pinned is None or self._pinned.numel() < B:
-            self._pinned = torch.empty(max(B, 1024), dtype=torch.long).pin_memory()
-        self._pinned[:B].copy_(torch.from_numpy(idx))
-        didx = self._pinned[:B].to(self.device, non_blocking=True)
+        didx = self._upload_indices(idx, B)
         ids = torch.empty(B, L, dtype=torch.long, device=self.device)
         mask = torch.empty(B, L, dtype=torch.long, device=self.device)
         rc = _lib.lib().bd_collate_batch(_lib.ptr(self._tok), _lib.ptr(self._off), _lib.ptr(didx), len(self.store), B, L,
@@ -47,6 +48,24 @@ class DeviceBatchLoader:
                                          _lib.stream_handle())
         _lib.check(rc, "bd_collate_batch")
         return {"input_ids": ids, "attention_mask": mask}
+
+    def _upload_indices(self, idx, B):
+        if len(self._ring) < self.ring_slots:
+            self._ring.append([torch.empty(max(B, 1024), dtype=torch.long).pin_memory(), None])
+            slot = self._ring[-1]
+        else:
+            slot = self._ring[self._ring_pos % self.ring_slots]
+            self._ring_pos += 1
+            if slot[1] is not None:
+                slot[1].synchronize()          # the upload that last read this buffer is done
+            if slot[0].numel() < B:
+                slot[0] = torch.empty(B, dtype=torch.long).pin_memory()
+        slot[0][:B].copy_(torch.from_numpy(idx))
+        didx = slot[0][:B].to(self.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        slot[1] = ev
+        return didx
 
     def __iter__(self):
         for batch in self.batch_sampler:

@@ -301,6 +301,10 @@ class DiffusionBackbone(nn.Module):
             timesteps = timesteps.squeeze(-1)
         if timesteps.shape[0] != input_ids.shape[0]:
             raise ValueError("timesteps must have one entry per sequence")
+        if input_ids.shape[1] > self.max_position_embeddings:
+            # nn.Embedding raises the same error type for a position past the table (reference backbone.py:238-243)
+            raise IndexError(f"sequence length {input_ids.shape[1]} exceeds max_position_embeddings "
+                             f"{self.max_position_embeddings}")
         return timesteps.to(device=input_ids.device, dtype=torch.long).contiguous()
 
     @staticmethod
@@ -351,7 +355,8 @@ class DiffusionBackbone(nn.Module):
         x = torch.empty(M, d, device=dev)
         _lib.check(L_.bd_embed(_lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(self.token_embedding.weight),
                                _lib.ptr(self.position_embedding.weight), _lib.ptr(self.timestep_embedding.weight),
-                               _lib.ptr(x), B, L, d, st), "bd_embed")
+                               _lib.ptr(x), B, L, d, self.vocab_size, self.max_position_embeddings,
+                               self.num_diffusion_steps + 1, st), "bd_embed")
         h = torch.empty(M, d, device=dev)
         qkv = torch.empty(M, 3 * d, device=dev)
         att = torch.empty(M, d, device=dev)

@@ -229,7 +229,8 @@ class _BackboneFn(torch.autograd.Function):
         x = torch.empty(M, d, device=dev)
         _ck(lib.bd_embed_drop(_lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(model.token_embedding.weight),
                               _lib.ptr(model.position_embedding.weight), _lib.ptr(model.timestep_embedding.weight),
-                              _lib.ptr(x), B, L, d, _dp(drop), 0, _s()), "bd_embed")
+                              _lib.ptr(x), B, L, d, V, model.max_position_embeddings, model.num_diffusion_steps + 1,
+                              _dp(drop), 0, _s()), "bd_embed")
         saved = []
         for li, (blk, w) in enumerate(zip(model.layers, tw.layers)):
             s = {"x_in": x}
@@ -408,7 +409,8 @@ class _BackboneFn(torch.autograd.Function):
             _ck(lib.bd_dropout_f32(_lib.ptr(dx), _lib.ptr(dx), M, d, _dp(drop), 0, _s()), "bd_dropout_f32")
         _ck(lib.bd_embed_bwd(_lib.ptr(dx), _lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(gbuf(model.token_embedding.weight)),
                              _lib.ptr(gbuf(model.position_embedding.weight)),
-                             _lib.ptr(gbuf(model.timestep_embedding.weight)), B, L, d, int(model.pad_token_id), _s()),
+                             _lib.ptr(gbuf(model.timestep_embedding.weight)), B, L, d, int(model.pad_token_id), V,
+                             model.max_position_embeddings, model.num_diffusion_steps + 1, _s()),
             "bd_embed_bwd")
         if side is not None:
             main.wait_stream(side)       # every gradient is complete before autograd / the optimizer go on

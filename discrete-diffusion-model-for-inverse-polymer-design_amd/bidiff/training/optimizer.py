@@ -43,15 +43,37 @@ class FlatAdamW(torch.optim.Optimizer):
                                  "exp_avg_sq": self.flat_v[off:off + k].view(p.shape)}
                 off += k
         self._params = params
+        self._offsets = []
+        off = 0
+        for p in params:
+            self._offsets.append(off)
+            off += p.numel()
 
     def zero_grad(self, set_to_none: bool = False):
         self.flat_grad.zero_()
-        off = 0
-        for p in self._params:       # keep .grad bound to the flat buffer
+        base = self.flat_grad.data_ptr()
+        for p, off in zip(self._params, self._offsets):       # keep .grad bound to the flat buffer
+            if p.grad is None or p.grad.data_ptr() != base + 4 * off:
+                p.grad = self.flat_grad[off:off + p.numel()].view(p.shape)
+
+    def sync_grads(self):
+        """Make the flat gradient buffer hold every parameter's gradient before it is reduced or consumed.
+        After ``model.zero_grad()`` (torch's default sets ``.grad`` to None) or ``p.grad = None`` the backward
+        pass hands gradients to autograd, which creates fresh ``.grad`` tensors beside the flat buffer: those are
+        copied into their slots and re-bound. A parameter without any gradient raises (the fused update always
+        covers the whole buffer)."""
+        base = self.flat_grad.data_ptr()
+        for p, off in zip(self._params, self._offsets):
+            g = p.grad
+            if g is not None and g.data_ptr() == base + 4 * off:
+                continue
+            if g is None:
+                raise RuntimeError("flat optimizer: a parameter has no gradient (was .grad set to None after the "
+                                   "backward pass?); use optimizer.zero_grad() between steps")
             k = p.numel()
-            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
-                p.grad = self.flat_grad[off:off + k].view(p.shape)
-            off += k
+            slot = self.flat_grad[off:off + k].view(p.shape)
+            slot.copy_(g)
+            p.grad = slot
 
     def grad_norm(self):
         """L2 norm of all gradients (device tensor, no host sync)."""
@@ -63,6 +85,7 @@ class FlatAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None, max_norm: float = 0.0):
         """One AdamW update; ``max_norm > 0`` first clips the global gradient norm to it."""
+        self.sync_grads()
         g = self.param_groups[0]
         self._step += 1
         b1, b2 = g["betas"]
@@ -182,6 +205,25 @@ class FlatMuonAdamW(torch.optim.Optimizer):
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
                 p.grad = self.flat_grad[off:off + p.numel()].view(p.shape)
 
+    def sync_grads(self):
+        """Make the flat gradient buffer hold every parameter's gradient before it is reduced or consumed.
+        After ``model.zero_grad()`` (torch's default sets ``.grad`` to None) or ``p.grad = None`` the backward
+        pass hands gradients to autograd, which creates fresh ``.grad`` tensors beside the flat buffer: those are
+        copied into their slots and re-bound. A parameter without any gradient raises (the fused update always
+        covers the whole buffer)."""
+        base = self.flat_grad.data_ptr()
+        for p, off in zip(self._params, self._offsets):
+            g = p.grad
+            if g is not None and g.data_ptr() == base + 4 * off:
+                continue
+            if g is None:
+                raise RuntimeError("flat optimizer: a parameter has no gradient (was .grad set to None after the "
+                                   "backward pass?); use optimizer.zero_grad() between steps")
+            k = p.numel()
+            slot = self.flat_grad[off:off + k].view(p.shape)
+            slot.copy_(g)
+            p.grad = slot
+
     def grad_norm(self):
         self._sumsq.zero_()
         _lib.check(_lib.lib().bd_sumsq_f32(_lib.ptr(self.flat_grad), self.numel, _lib.ptr(self._sumsq),
@@ -192,6 +234,7 @@ class FlatMuonAdamW(torch.optim.Optimizer):
     def step(self, closure=None, max_norm: float = 0.0):
         """One update of both groups; ``max_norm > 0`` first clips the global gradient norm (all
         parameters of both groups) to it."""
+        self.sync_grads()
         lib, s = _lib.lib(), _lib.stream_handle()
         self._step += 1
         ss = None

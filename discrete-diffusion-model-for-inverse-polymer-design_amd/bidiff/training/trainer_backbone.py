@@ -111,6 +111,7 @@ class BackboneTrainer:
         loss.backward()
         if should_step:
             if self.distributed:
+                self.optimizer.sync_grads()
                 allreduce_mean_(self.optimizer.flat_grad, self.world_size)
             self.optimizer.step(max_norm=self.gradient_clip_norm)
             self.optimizer.zero_grad()
@@ -200,7 +201,7 @@ class BackboneTrainer:
         if not math.isnan(val_loss) and val_loss < self.best_val_loss:
             self.best_val_loss = val_loss
             torch.save(self._checkpoint(val_loss, epoch), self.checkpoint_dir / "backbone_best.pt")
-        if final and (self.save_last or not self.save_best_only):
+        if final and not self.save_best_only and self.save_last:      # reference trainer_backbone.py:631
             torch.save(self._checkpoint(val_loss, epoch), self.checkpoint_dir / "backbone_last.pt")
 
     def _save_history(self):
@@ -212,11 +213,19 @@ class BackboneTrainer:
                 w = csv.writer(f)
                 w.writerow(header)
                 w.writerows(rows)
-        dump("backbone_loss_curve.csv", ["step", "train_loss", "learning_rate"],
-             [(i, l, lr) for i, (l, lr) in enumerate(zip(self.train_losses, self.learning_rates))])
-        dump("backbone_val_loss.csv", ["step", "val_loss"], list(zip(self.val_steps, self.val_losses)))
-        dump("backbone_epoch_loss_curve.csv", ["epoch", "train_loss", "val_loss"],
-             [(i + 1, a, b) for i, (a, b) in enumerate(zip(self.epoch_train_losses, self.epoch_val_losses))])
+        # same columns and rounding as the reference (trainer_backbone.py:654-692): losses and bits per byte
+        # (loss / ln 2) to 4 decimals, learning rate to 8
+        bpb = 1.0 / math.log(2.0)
+        r4 = lambda v: round(v, 4)  # noqa: E731
+        dump("backbone_loss_curve.csv", ["step", "train_loss", "train_bpb", "learning_rate"],
+             [(i, r4(l), r4(l * bpb), round(lr, 8)) for i, (l, lr) in enumerate(zip(self.train_losses, self.learning_rates))])
+        if self.val_losses and self.val_steps:
+            dump("backbone_val_loss.csv", ["step", "val_loss", "val_bpb"],
+                 [(st, r4(v), r4(v * bpb)) for st, v in zip(self.val_steps, self.val_losses)])
+        if self.epoch_train_losses and self.epoch_val_losses:
+            dump("backbone_epoch_loss_curve.csv", ["epoch", "train_loss", "val_loss", "train_bpb", "val_bpb"],
+                 [(i + 1, r4(a), r4(b), r4(a * bpb), r4(b * bpb))
+                  for i, (a, b) in enumerate(zip(self.epoch_train_losses, self.epoch_val_losses))])
 
     def load_checkpoint(self, checkpoint_path: str):
         ck = torch.load(checkpoint_path, map_location=self.device, weights_only=False)  # file written by this class
@@ -224,4 +233,4 @@ class BackboneTrainer:
         self.optimizer.load_state_dict(ck["optimizer_state_dict"])
         self.scheduler.load_state_dict(ck["scheduler_state_dict"])
         self.global_step = ck["global_step"]
-        self.best_val_loss = ck["best_val_loss"]
+        self.best_val_loss = ck.get("best_val_loss", float("inf"))    # periodic checkpoints carry no such key

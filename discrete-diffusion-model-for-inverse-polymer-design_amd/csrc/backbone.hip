@@ -85,7 +85,7 @@ int forward_impl(const bd_backbone_desc* desc, const long long* ids, const long 
       return bd_gemm_bf16(hf, c.w_out, nullptr, logits_out, Mi, c.vocab_pad, c.vocab, d, c.vocab, 3, stream);
     return BD_OK;
   }
-  if ((rc = bd_embed(ids, timesteps, c.tok_emb, c.pos_emb, c.time_emb, x, B, L, d, stream))) return rc;
+  if ((rc = bd_embed(ids, timesteps, c.tok_emb, c.pos_emb, c.time_emb, x, B, L, d, c.vocab, c.max_pos, c.n_timesteps, stream))) return rc;
   // Fused kernels whenever the shapes allow: the whole attention block in one kernel per sequence
   // and the whole feed-forward block in one kernel per 128-token panel (nothing but the residual
   // stream touches memory). Otherwise LayerNorm folded into the row-panel projection kernel, or

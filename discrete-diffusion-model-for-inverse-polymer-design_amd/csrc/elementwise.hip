@@ -15,12 +15,20 @@ __global__ __launch_bounds__(256) void embed_kernel(const long long* __restrict_
                                                     const float* __restrict__ pos,
                                                     const float* __restrict__ tim,
                                                     float* __restrict__ x, int M, int L, int d,
-                                                    bd_drop_args drop) {
+                                                    int vocab, int n_timesteps, bd_drop_args drop) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const long long id = ids[row];
   const long long t = tsteps[row / L];
+  if (id < 0 || id >= vocab || t < 0 || t >= n_timesteps) {
+    // an index outside its table (nn.Embedding raises there): never read past the table, and make the
+    // row NaN so that the logits and the loss of this batch are visibly invalid
+    f32x4* o = (f32x4*)(x + (size_t)row * d);
+    const float q = __int_as_float(0x7fc00000);
+    for (int i = lane; i < d / 4; i += 64) { f32x4 r; r[0] = q; r[1] = q; r[2] = q; r[3] = q; o[i] = r; }
+    return;
+  }
   const f32x4* a = (const f32x4*)(tok + (size_t)id * d);
   const f32x4* b = (const f32x4*)(pos + (size_t)(row % L) * d);
   const f32x4* c = (const f32x4*)(tim + (size_t)t * d);
@@ -300,8 +308,10 @@ __global__ __launch_bounds__(256) void mask_to_bytes_kernel(const long long* __r
 }  // namespace
 
 extern "C" int bd_embed(const long long* ids, const long long* timesteps, const float* tok_emb,
-                        const float* pos_emb, const float* time_emb, float* x, int B, int L, int d, void* stream) {
-  return bd_embed_drop(ids, timesteps, tok_emb, pos_emb, time_emb, x, B, L, d, nullptr, 0u, stream);
+                        const float* pos_emb, const float* time_emb, float* x, int B, int L, int d, int vocab,
+                        int max_pos, int n_timesteps, void* stream) {
+  return bd_embed_drop(ids, timesteps, tok_emb, pos_emb, time_emb, x, B, L, d, vocab, max_pos, n_timesteps, nullptr,
+                       0u, stream);
 }
 
 extern "C" int bd_pool_hidden(const void* hidden_bf16, const long long* attention_mask, float* out, int B, int L,
@@ -349,15 +359,18 @@ extern "C" int bd_dropout_f32_to_bf16(const float* x, void* out, int M, int N, c
 
 extern "C" int bd_embed_drop(const long long* ids, const long long* timesteps, const float* tok_emb,
                              const float* pos_emb, const float* time_emb, float* x, int B, int L, int d,
-                             const bd_dropout* drop, unsigned site, void* stream) {
+                             int vocab, int max_pos, int n_timesteps, const bd_dropout* drop, unsigned site,
+                             void* stream) {
   BD_REQUIRE(ids && timesteps && tok_emb && pos_emb && time_emb && x, "bd_embed: null operand");
+  BD_REQUIRE(vocab > 0 && n_timesteps > 0, "bd_embed: empty table (vocab=%d, timesteps=%d)", vocab, n_timesteps);
+  BD_REQUIRE(L <= max_pos, "bd_embed: sequence length %d exceeds max_position_embeddings %d", L, max_pos);
   bd_drop_args da;
   BD_REQUIRE(bd_drop_make(drop, site, &da), "bd_embed: dropout p=%g outside [0, 1)", (double)drop->p);
   BD_REQUIRE(B > 0 && L > 0 && d > 0 && d % 4 == 0, "bd_embed: bad shape B=%d L=%d d=%d", B, L, d);
   const long long M = (long long)B * L;
   BD_REQUIRE(M < (1ll << 31), "bd_embed: too many tokens");
   hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ids,
-                     timesteps, tok_emb, pos_emb, time_emb, x, (int)M, L, d, da);
+                     timesteps, tok_emb, pos_emb, time_emb, x, (int)M, L, d, vocab, n_timesteps, da);
   return bd_check_launch("bd_embed");
 }
 

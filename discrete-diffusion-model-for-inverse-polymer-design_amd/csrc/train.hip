@@ -785,7 +785,8 @@ constexpr int EB_MAXL = 1024;    // longest sequence of embed_bwd_seq_kernel
 
 __global__ __launch_bounds__(256) void embed_bwd_seq_kernel(const float* __restrict__ dx, const long long* __restrict__ ids,
                                                             const long long* __restrict__ tsteps, float* __restrict__ dtok,
-                                                            float* __restrict__ dtim, int L, int d, int pad_id) {
+                                                            float* __restrict__ dtim, int L, int d, int pad_id,
+                                                            int vocab, int n_timesteps) {
   // Rows of one sequence sorted by token id (rank sort in LDS), so that rows sharing a token - the mask token is
   // half of a corrupted sequence - are summed in registers and reach the token's row as one atomic per sequence:
   // same-address atomics retire one after another (about 36 ns each), 5000 mask rows of a batch took 180 us.
@@ -802,7 +803,10 @@ __global__ __launch_bounds__(256) void embed_bwd_seq_kernel(const float* __restr
     sord[rank] = (short)l;
   }
   __syncthreads();
-  float* c = dtim + (size_t)tsteps[b] * d;
+  // indices outside their tables (the forward made those rows NaN) add nothing and touch no memory
+  const long long ts = tsteps[b];
+  const bool ts_ok = ts >= 0 && ts < n_timesteps;
+  float* c = dtim + (size_t)(ts_ok ? ts : 0) * d;
   for (int i = threadIdx.x; i < d; i += 256) {
     float tsum = 0.f, run = 0.f;
     int run_id = -1;
@@ -815,7 +819,7 @@ __global__ __launch_bounds__(256) void embed_bwd_seq_kernel(const float* __restr
         if (r0 + u >= L) break;
         const int id = sid[sord[r0 + u]];
         if (id != run_id) {
-          if (run != 0.f && run_id != pad_id) atomicAdd(dtok + (size_t)run_id * d + i, run);
+          if (run != 0.f && run_id != pad_id && run_id >= 0 && run_id < vocab) atomicAdd(dtok + (size_t)run_id * d + i, run);
           run = 0.f;
           run_id = id;
         }
@@ -823,8 +827,8 @@ __global__ __launch_bounds__(256) void embed_bwd_seq_kernel(const float* __restr
         tsum += v[u];
       }
     }
-    if (run != 0.f && run_id != pad_id) atomicAdd(dtok + (size_t)run_id * d + i, run);
-    if (tsum != 0.f) atomicAdd(c + i, tsum);
+    if (run != 0.f && run_id != pad_id && run_id >= 0 && run_id < vocab) atomicAdd(dtok + (size_t)run_id * d + i, run);
+    if (tsum != 0.f && ts_ok) atomicAdd(c + i, tsum);
   }
 }
 
@@ -1186,11 +1190,14 @@ extern "C" int bd_attention_bwd_drop(const void* qkv, const unsigned char* keyma
 }
 
 extern "C" int bd_embed_bwd(const float* dx, const long long* ids, const long long* timesteps, float* dtok,
-                            float* dpos, float* dtime, int B, int L, int d, int pad_id, void* stream) {
+                            float* dpos, float* dtime, int B, int L, int d, int pad_id, int vocab, int max_pos,
+                            int n_timesteps, void* stream) {
   BD_REQUIRE(dx && ids && timesteps && dtok && dpos && dtime, "bd_embed_bwd: null operand");
+  BD_REQUIRE(vocab > 0 && n_timesteps > 0, "bd_embed_bwd: empty table");
+  BD_REQUIRE(L <= max_pos, "bd_embed_bwd: sequence length %d exceeds max_position_embeddings %d", L, max_pos);
   BD_REQUIRE(B > 0 && L > 0 && L <= EB_MAXL && d > 0, "bd_embed_bwd: bad shape B=%d L=%d d=%d", B, L, d);
   hipLaunchKernelGGL(embed_bwd_seq_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, dx, ids, timesteps, dtok,
-                     dtime, L, d, pad_id);
+                     dtime, L, d, pad_id, vocab, n_timesteps);
   // enough workgroups to fill the chip: the batch is cut into slices when there are few positions
   const int slices = L >= 512 ? 1 : (512 + L - 1) / L;
   hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3((unsigned)L, (unsigned)(slices < B ? slices : B)), dim3(256), 0,

@@ -38,10 +38,12 @@ int bd_device_available(void);
 /* ---------------------------------------------------------------- denoiser forward */
 
 /* x[b,l,:] = tok_emb[ids[b,l]] + pos_emb[l] + time_emb[timesteps[b]]   (fp32)
+ * vocab / max_pos / n_timesteps are the row counts of the three tables: L > max_pos is rejected; a token id or
+ * timestep outside its table (nn.Embedding raises there) reads nothing and makes that row NaN.
  * replaces src/model/backbone.py:234-246 (three nn.Embedding lookups and their sum). */
 int bd_embed(const long long* ids, const long long* timesteps, const float* tok_emb,
-             const float* pos_emb, const float* time_emb, float* x, int B, int L, int d,
-             void* stream);
+             const float* pos_emb, const float* time_emb, float* x, int B, int L, int d, int vocab,
+             int max_pos, int n_timesteps, void* stream);
 
 /* LayerNorm over the last dim (eps 1e-5 in the reference), fp32 in; writes bf16 and/or
  * fp32 output and optionally per-row (mean, rstd) for the backward pass.
@@ -279,7 +281,7 @@ int bd_dropout_f32_to_bf16(const float* x, void* out_bf16, int M, int N, const b
 /* bd_embed followed by dropout of the sum (src/model/backbone.py:247). */
 int bd_embed_drop(const long long* ids, const long long* timesteps, const float* tok_emb,
                   const float* pos_emb, const float* time_emb, float* x, int B, int L, int d,
-                  const bd_dropout* drop, unsigned site, void* stream);
+                  int vocab, int max_pos, int n_timesteps, const bd_dropout* drop, unsigned site, void* stream);
 
 /* bd_gemm_bf16_aux with dropout in the epilogue (row = m, column = n of the output):
  *   epilogue 1: out = drop(gelu(acc + bias))            (src/model/backbone.py:97-98)
@@ -346,9 +348,11 @@ int bd_attention_bwd_drop(const void* qkv, const unsigned char* keymask, const v
                           const bd_dropout* drop, unsigned site, void* stream);
 
 /* Scatter-add of the embedding-sum gradient into the three tables (the pad row of the token table
- * receives nothing, as nn.Embedding(padding_idx) does). (autograd of src/model/backbone.py:234-246). */
+ * receives nothing, as nn.Embedding(padding_idx) does). Table sizes as in bd_embed: L > max_pos is rejected,
+ * rows whose index lies outside its table add nothing. (autograd of src/model/backbone.py:234-246). */
 int bd_embed_bwd(const float* dx, const long long* ids, const long long* timesteps, float* dtok, float* dpos,
-                 float* dtime, int B, int L, int d, int pad_id, void* stream);
+                 float* dtime, int B, int L, int d, int pad_id, int vocab, int max_pos, int n_timesteps,
+                 void* stream);
 
 /* out[0] += sum x^2 (global gradient norm of clip_grad_norm_, src/training/trainer_backbone.py:446-449). */
 int bd_sumsq_f32(const float* x, long long n, float* out, void* stream);

@@ -130,6 +130,35 @@ def test_device_loader_batches_equal_reference(gpu_device):
 
 
 @pytest.mark.gpu
+def test_device_loader_host_running_ahead_of_the_stream(gpu_device):
+    """Many batches assembled back to back behind a long-running kernel, no synchronisation in between:
+    every batch must still hold its own rows (the pinned index buffers rotate and are rewritten only after
+    the upload that read them has finished)."""
+    dev = gpu_device
+    rs = np.random.RandomState(3)
+    lens = rs.randint(2, 60, size=3000)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    tokens = rs.randint(5, 500, size=int(offsets[-1])).astype(np.uint16)
+    store = TokenStore(tokens, offsets, 0, 60)
+    loader = DeviceBatchLoader(store, None, dev, pad_to_max_length=True)
+    a = torch.randn(6144, 6144, device=dev)
+    torch.cuda.synchronize()
+    for _ in range(12):           # a few hundred ms of queued work the uploads have to wait behind
+        a = (a @ a).clamp_(-1, 1)
+    batches, want = [], []
+    for i in range(3 * loader.ring_slots + 2):
+        idx = rs.randint(0, 3000, size=64)
+        batches.append(loader.assemble(idx))
+        want.append(idx)
+    torch.cuda.synchronize()
+    for batch, idx in zip(batches, want):
+        ids, mask = DR.dynamic_collate([store.row(i) for i in idx], 0)
+        got = batch["input_ids"].cpu().numpy()
+        assert np.array_equal(got[:, :ids.shape[1]], ids) and (got[:, ids.shape[1]:] == 0).all()
+    loader.check()
+
+
+@pytest.mark.gpu
 def test_collate_kernel_flags_bad_rows_and_large_batches(gpu_device):
     from bidiff import _lib
     dev = gpu_device

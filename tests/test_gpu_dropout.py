@@ -79,7 +79,7 @@ def test_embedding_dropout(gpu_device):
     drop = _lib.Dropout(0.1, 7, 99)
     x = torch.empty(B * L, d, device=dev)
     args = [a.to(dev) for a in (ids, t, tok, pos, tim)]
-    _lib.check(_lib.lib().bd_embed_drop(*[_lib.ptr(a) for a in args], _lib.ptr(x), B, L, d, C.byref(drop), 0, _s()), "embed")
+    _lib.check(_lib.lib().bd_embed_drop(*[_lib.ptr(a) for a in args], _lib.ptr(x), B, L, d, V, 64, T + 1, C.byref(drop), 0, _s()), "embed")
     want = ((tok[ids] + pos[:L][None]) + tim[t][:, None, :]).view(B * L, d) * factors(drop, 0, B * L, d)
     assert torch.equal(x.cpu(), want)
 

@@ -158,11 +158,28 @@ def test_embed(gpu_device):
     x = torch.empty(B * L, d, device=dev)
     dv = [a.to(dev) for a in (ids, t, tok, pos, tim)]
     rc = _lib.lib().bd_embed(_lib.ptr(dv[0]), _lib.ptr(dv[1]), _lib.ptr(dv[2]), _lib.ptr(dv[3]),
-                             _lib.ptr(dv[4]), _lib.ptr(x), B, L, d, _s())
+                             _lib.ptr(dv[4]), _lib.ptr(x), B, L, d, V, 64, T, _s())
     _lib.check(rc, "embed")
     torch.cuda.synchronize()
     ref = tok[ids] + pos[:L][None] + tim[t][:, None]
     assert torch.equal(x.cpu().view(B, L, d), ref)
+    # a sequence longer than the position table is rejected; an id or timestep outside its table reads
+    # nothing and marks its row (nn.Embedding raises for all three)
+    assert _lib.lib().bd_embed(_lib.ptr(dv[0]), _lib.ptr(dv[1]), _lib.ptr(dv[2]), _lib.ptr(dv[3]),
+                               _lib.ptr(dv[4]), _lib.ptr(x), B, L, d, V, L - 1, T, _s()) != 0
+    bad = ids.clone()
+    bad[1, 3] = V
+    bad[2, 0] = -1
+    tb = t.clone()
+    tb[3] = T
+    _lib.check(_lib.lib().bd_embed(_lib.ptr(bad.to(dev)), _lib.ptr(tb.to(dev)), _lib.ptr(dv[2]), _lib.ptr(dv[3]),
+                                   _lib.ptr(dv[4]), _lib.ptr(x), B, L, d, V, 64, T, _s()), "embed")
+    got = x.cpu().view(B, L, d)
+    nan_rows = torch.isnan(got).all(-1)
+    want = torch.zeros(B, L, dtype=torch.bool)
+    want[1, 3] = want[2, 0] = True
+    want[3] = True
+    assert torch.equal(nan_rows, want) and torch.equal(got[~want], ref[~want])
 
 
 def test_bad_arguments_are_rejected(gpu_device):

@@ -220,7 +220,7 @@ def test_embedding_backward(gpu_device, B, L, d, V):
     dtok, dpos, dtim = torch.zeros(V, d, device=dev), torch.zeros(max(64, L), d, device=dev), torch.zeros(T, d, device=dev)
     a, b, c = ids.to(dev), t.to(dev), dx.to(dev)
     _lib.check(_lib.lib().bd_embed_bwd(_lib.ptr(c), _lib.ptr(a), _lib.ptr(b), _lib.ptr(dtok), _lib.ptr(dpos), _lib.ptr(dtim),
-                                       B, L, d, 0, _s()), "embed bwd")
+                                       B, L, d, 0, V, max(64, L), T, _s()), "embed bwd")
     torch.cuda.synchronize()
     tok = torch.nn.Embedding(V, d, padding_idx=0)
     pos, tim = torch.nn.Embedding(max(64, L), d), torch.nn.Embedding(T, d)
@@ -331,6 +331,33 @@ def test_training_with_padded_heads_matches_oracle_autograd(gpu_device):
         assert rel(p.grad.cpu(), ref_sd[k].grad) < 1e-1 and cos > 0.995, (k, cos)
 
 
+def test_training_path_rejects_sequences_longer_than_the_position_table(gpu_device):
+    """L = max_position_embeddings + 1 raises on the training path and in fp32 mode, like the reference's
+    nn.Embedding does (no read past the table, no gradient written past it)."""
+    dev = gpu_device
+    cfg, model, sd, ids, attn, t = _grad_setup("tiny_h2", dev)
+    L = cfg["max_position_embeddings"] + 1
+    long_ids = torch.full((2, L), 7, dtype=torch.long, device=dev)
+    tt = torch.ones(2, dtype=torch.long, device=dev)
+    model.train()
+    with pytest.raises(IndexError, match="max_position_embeddings"):
+        model.backbone(long_ids, tt, torch.ones_like(long_ids))
+    model.eval()
+    with torch.no_grad(), pytest.raises(IndexError, match="max_position_embeddings"):
+        model.backbone(long_ids, tt, torch.ones_like(long_ids))
+    model.backbone.compute_dtype = "fp32"
+    with torch.no_grad(), pytest.raises(IndexError, match="max_position_embeddings"):
+        model.backbone(long_ids, tt, torch.ones_like(long_ids))
+    # the C entry points reject it too
+    x = torch.empty(2 * L, cfg["hidden_size"], device=dev)
+    bb = model.backbone
+    rc = _lib.lib().bd_embed_bwd(_lib.ptr(x), _lib.ptr(long_ids), _lib.ptr(tt), _lib.ptr(bb.token_embedding.weight),
+                                 _lib.ptr(bb.position_embedding.weight), _lib.ptr(bb.timestep_embedding.weight), 2, L,
+                                 cfg["hidden_size"], 0, cfg["vocab_size"], cfg["max_position_embeddings"],
+                                 cfg["num_diffusion_steps"] + 1, _s())
+    assert rc != 0 and b"max_position_embeddings" in _lib.lib().bd_last_error()
+
+
 def test_backward_into_bound_gradients_equals_autograd_accumulation(gpu_device):
     """With .grad tensors already bound (FlatAdamW) the backward kernels add straight into them;
     the result must equal what autograd's own accumulation gives, including over two micro-steps."""
@@ -354,6 +381,40 @@ def test_backward_into_bound_gradients_equals_autograd_accumulation(gpu_device):
         # atomic accumulation order differs between launches: compare with a small tolerance
         assert rel(p.grad.cpu(), 2.0 * ref[k].cpu()) < 1e-4 or ref[k].abs().max().item() < 1e-12, k
     assert opt.flat_grad.data_ptr() == next(iter(model.parameters())).grad.data_ptr()
+
+
+def test_optimizer_picks_up_gradients_unbound_by_model_zero_grad(gpu_device):
+    """model.zero_grad() (torch's default sets .grad to None) unbinds the flat buffer: autograd then creates fresh
+    .grad tensors. The step must consume those (copied into the flat buffer and re-bound), not the stale buffer,
+    and a parameter left without a gradient raises."""
+    dev = gpu_device
+    cfg, model, sd, ids, attn, t = _grad_setup("tiny_h2", dev)
+    model.train()
+    u = torch.rand(ids.shape, generator=torch.Generator().manual_seed(1))
+
+    def fwd_bwd():
+        noisy, ind = model.forward_process(ids.to(dev), t.to(dev), attn.to(dev), uniforms=u.to(dev))
+        model._compute_loss(model.backbone(noisy, t.to(dev), attn.to(dev)), ids.to(dev), ind, attn.to(dev)).backward()
+
+    opt = FlatAdamW(model.parameters(), lr=1e-3)
+    opt.zero_grad()
+    fwd_bwd()
+    ref = opt.flat_grad.clone()
+    opt.flat_grad.fill_(123.0)                 # stale content the step must not consume
+    model.zero_grad()                          # .grad = None everywhere
+    fwd_bwd()
+    assert all(p.grad is not None and p.grad.data_ptr() != opt.flat_grad.data_ptr() for p in list(model.parameters())[1:])
+    opt.sync_grads()
+    assert rel(opt.flat_grad.cpu(), ref.cpu()) < 1e-4
+    base = opt.flat_grad.data_ptr()
+    assert all(p.grad.data_ptr() == base + 4 * off for p, off in zip(opt._params, opt._offsets))
+    before = opt.flat_param.clone()
+    opt.step(max_norm=1.0)
+    assert not torch.equal(before, opt.flat_param)
+    opt.zero_grad()
+    next(iter(model.parameters())).grad = None
+    with pytest.raises(RuntimeError, match="no gradient"):
+        opt.step()
 
 
 def test_training_steps_follow_fp32_reference_trajectory(gpu_device):
@@ -405,8 +466,19 @@ def test_trainer_runs_and_checkpoints(gpu_device, tmp_path):
     assert set(ck) == {"epoch", "global_step", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict",
                        "val_loss", "best_val_loss", "config"}
     assert list(ck["model_state_dict"].keys()) == list(sd.keys())
-    assert (tmp_path / "metrics" / "backbone_loss_curve.csv").exists()
+    head = (tmp_path / "metrics" / "backbone_loss_curve.csv").read_text().splitlines()[0]
+    assert head == "step,train_loss,train_bpb,learning_rate"
+    assert (tmp_path / "metrics" / "backbone_val_loss.csv").read_text().splitlines()[0] == "step,val_loss,val_bpb"
+    assert (tmp_path / "metrics" / "backbone_epoch_loss_curve.csv").read_text().splitlines()[0] == \
+        "epoch,train_loss,val_loss,train_bpb,val_bpb"
+    # save_best_only=True: no final checkpoint, whatever save_last says (reference trainer_backbone.py:631)
+    assert not (tmp_path / "checkpoints" / "backbone_last.pt").exists()
     tr.load_checkpoint(str(tmp_path / "checkpoints" / "backbone_best.pt"))
+    # a periodic checkpoint of the reference has no best_val_loss key
+    del ck["best_val_loss"], ck["val_loss"], ck["config"]
+    torch.save(ck, tmp_path / "periodic.pt")
+    tr.load_checkpoint(str(tmp_path / "periodic.pt"))
+    assert tr.best_val_loss == float("inf")
 
 
 def test_multi_cast_jobs(gpu_device):

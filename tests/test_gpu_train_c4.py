@@ -1,0 +1,84 @@
+"""The SMILES_BPE training step at the shape the throughput figure is quoted on: V = 803, d 384 / 6 layers /
+3 heads (head size 128) / ffn 1536, T = 50, L = 128 padded, per-GPU batch 256 with the benchmark's length
+distribution. Loss and every one of the 102 parameter gradients against fp32 autograd of the CPU restatement
+(reference: trainer_backbone.py:414-457 -> diffusion.py:129-209 -> backbone.py:215-257), without dropout at
+B = 256 and with dropout 0.1 at all four sites (shared counter-based decision stream) at B = 64."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import backbone_ref as BR
+from bidiff.model.backbone import DiffusionBackbone
+from bidiff.model.diffusion import DiscreteMaskingDiffusion
+
+pytestmark = pytest.mark.gpu
+V, T, L = 803, 50, 128
+
+
+def rel(a, b):
+    return float((a - b).norm() / b.norm().clamp(min=1e-12))
+
+
+def c4_batch(batch, seed=1):
+    rs = np.random.RandomState(seed)
+    lens = np.clip(np.round(rs.normal(38.5, 15.0, size=batch)), 12, L).astype(np.int64)
+    ids = rs.randint(5, V, size=(batch, L)).astype(np.int64)
+    attn = (np.arange(L)[None] < lens[:, None]).astype(np.int64)
+    ids[attn == 0] = 0
+    ids[:, 0] = 2
+    ids[np.arange(batch), lens - 1] = 3
+    t = rs.randint(1, T + 1, size=batch).astype(np.int64)
+    u = rs.random_sample((batch, L)).astype(np.float32)
+    return torch.from_numpy(ids), torch.from_numpy(attn), torch.from_numpy(t), torch.from_numpy(u)
+
+
+@pytest.mark.parametrize("batch,p", [(256, 0.0), (64, 0.1)])
+def test_bpe_training_step_at_benchmark_shape(gpu_device, batch, p):
+    dev = gpu_device
+    cfg = dict(vocab_size=V, hidden_size=384, num_layers=6, num_heads=3, ffn_hidden_size=1536,
+               max_position_embeddings=256, num_diffusion_steps=T, dropout=p, pad_token_id=0)
+    torch.manual_seed(42)
+    bb = DiffusionBackbone(**cfg)
+    model = DiscreteMaskingDiffusion(bb, num_steps=T, mask_token_id=1, pad_token_id=0, bos_token_id=2, eos_token_id=3)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(dev).train()
+    ids, attn, t, u = c4_batch(batch)
+    bb.dropout_seed, bb._drop_step = 0x5EED5EED1234, 3
+    noisy, ind = model.forward_process(ids.to(dev), t.to(dev), attn.to(dev), uniforms=u.to(dev))
+    logits = bb(noisy, t.to(dev), attn.to(dev))
+    loss = model._compute_loss(logits, ids.to(dev), ind, attn.to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+
+    stream = BR.DropoutStream(p, bb.dropout_seed, 3) if p > 0 else None
+    ref_sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and k != "mask_schedule") for k, v in sd.items()}
+    rl = BR.logits(ref_sd, cfg, noisy.cpu(), t, attn, prefix="backbone.", dropout=stream)
+    rloss = BR.masked_ce(rl, ids, ind.cpu(), attn)
+    rloss.backward()
+    # corruption is bit-exact against the reference formula on the same uniforms
+    sched = BR.mask_schedule(T)
+    want = (u < sched[t][:, None]) & (attn == 1) & (ids != 2) & (ids != 3)
+    assert torch.equal(ind.cpu(), want)
+    # logits: north-star tolerance for bf16 compute
+    real = attn.bool()
+    err = (logits.detach().cpu()[real] - rl.detach()[real]).abs().max().item() / rl.detach()[real].abs().max().item()
+    assert err < 2e-2, err
+    assert abs(loss.item() - rloss.item()) < 5e-3 * abs(rloss.item()), (loss.item(), rloss.item())
+    worst, worst_cos, n = 0.0, 1.0, 0
+    for k, prm in model.named_parameters():
+        gref = ref_sd[k].grad
+        assert prm.grad is not None and torch.isfinite(prm.grad).all(), k
+        n += 1
+        if k.endswith("k_proj.bias"):
+            # the key bias shifts every score of a query equally: its true gradient is zero
+            qb = ref_sd[k.replace("k_proj", "q_proj")].grad.norm().item()
+            assert prm.grad.norm().item() < 0.1 * qb, k
+            continue
+        e = rel(prm.grad.cpu(), gref)
+        cos = torch.nn.functional.cosine_similarity(prm.grad.cpu().flatten(), gref.flatten(), dim=0).item()
+        worst, worst_cos = max(worst, e), min(worst_cos, cos)
+        assert e < 5e-2 and cos > 0.998, (k, e, cos)
+    assert n == 102
+    print(f"C4 shape B={batch} p={p}: logits rel err {err:.2e}, loss {loss.item():.5f} vs {rloss.item():.5f}, "
+          f"worst gradient rel err {worst:.3e}, worst cosine {worst_cos:.5f}")
+    assert model.backbone.token_embedding.weight.grad[0].abs().max().item() == 0.0

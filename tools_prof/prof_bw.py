@@ -49,7 +49,7 @@ ob = torch.empty(M, d, dtype=torch.bfloat16, device=dev)
 timeit("layernorm_kernel M=524288 d=384", lambda: lib.bd_layernorm(P(x), P(gm), P(bt), P(ob), None, None, M, d, 1e-5, s()), M * d * 6)
 ids = torch.randint(0, 39, (4096, 128), device=dev); tt = torch.randint(1, 101, (4096,), device=dev)
 te, pe, me = torch.randn(39, d, device=dev), torch.randn(256, d, device=dev), torch.randn(101, d, device=dev)
-timeit("embed_kernel B=4096 L=128 d=384", lambda: lib.bd_embed(P(ids), P(tt), P(te), P(pe), P(me), P(x), 4096, 128, d, s()), M * d * 4 + M * 8,
+timeit("embed_kernel B=4096 L=128 d=384", lambda: lib.bd_embed(P(ids), P(tt), P(te), P(pe), P(me), P(x), 4096, 128, d, te.shape[0], pe.shape[0], me.shape[0], s()), M * d * 4 + M * 8,
        note="tables are cache resident; bytes = output + ids")
 # optimizer over the flat buffers of the BPE small model
 n = 11382144
