@@ -557,7 +557,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned shor
   dl += __shfl_xor(dl, 16, 64);
   dl += __shfl_xor(dl, 32, 64);
   const float lq = lse[((size_t)b * H + h) * L + qr];
-  if (qok && g == 0) delta[((size_t)b * H + h) * L + qr] = dl;
+  // delta_i = sum_j P_ij dP_ij. With all keys in one tile (L <= 128) it is summed from the very P and dP that
+  // form dS below, in fp32, so that sum_j dS_ij = 0 holds to rounding: rowsum(dO * O) from the bf16-rounded O
+  // misses that by 2^-9 of |dO||O|, which is as large as dS itself when the attention is nearly uniform (the
+  // q / k gradients of a freshly initialised model came out 13 % off). Longer sequences keep rowsum(dO * O).
+  const bool one_tile = L <= AT;
+  if (!one_tile && qok && g == 0) delta[((size_t)b * H + h) * L + qr] = dl;
 
   f32x4 acc[DT];
 #pragma unroll
@@ -581,10 +586,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned shor
     stage_rows<DH>(Ks, qkv + (size_t)b * L * row3 + d + (size_t)h * DH, row3, kt0, L, tid, live);
     stage_rows<DH>(Vs, qkv + (size_t)b * L * row3 + 2 * d + (size_t)h * DH, row3, kt0, L, tid, live);
     __syncthreads();
-    bf16x8 dsf[4];
+    float pv[4][8], dv[4][8];
+    float psum = 0.f;
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
-      bf16x8 frag;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { pv[s4][e] = 0.f; dv[s4][e] = 0.f; }
       if (!((live >> s4) & 1u)) continue;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
@@ -608,9 +615,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned shor
         for (int r = 0; r < 4; ++r) {
           const bool vis = ((m4 >> (8 * r)) & 0xffu) != 0u && lq > -INFINITY;
           const float p = vis ? __expf(s[r] * scale - lq) : 0.f;
-          frag[4 * half + r] = (__bf16)(p * (dp[r] - dl) * scale);
+          pv[s4][4 * half + r] = p;
+          dv[s4][4 * half + r] = dp[r];
+          psum += p * dp[r];
         }
       }
+    }
+    if (one_tile) {
+      psum += __shfl_xor(psum, 16, 64);
+      psum += __shfl_xor(psum, 32, 64);
+      dl = psum;
+      if (qok && g == 0) delta[((size_t)b * H + h) * L + qr] = dl;
+    }
+    bf16x8 dsf[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      bf16x8 frag;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) frag[e] = (__bf16)(pv[s4][e] * (dv[s4][e] - dl) * scale);
       dsf[s4] = frag;
     }
     // dQ^T += K^T dS^T

@@ -55,6 +55,13 @@ def test_bpe_training_step_at_benchmark_shape(gpu_device, batch, p):
     rl = BR.logits(ref_sd, cfg, noisy.cpu(), t, attn, prefix="backbone.", dropout=stream)
     rloss = BR.masked_ce(rl, ids, ind.cpu(), attn)
     rloss.backward()
+    # the same restatement under bf16 autocast (the precision the reference trains in, trainer_backbone.py:434):
+    # its distance from fp32 is the yardstick for the tensors whose gradient is a small difference of large terms
+    # (q / k projections of a freshly initialised model, where the attention is nearly uniform)
+    ac_sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and k != "mask_schedule") for k, v in sd.items()}
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        al = BR.logits(ac_sd, cfg, noisy.cpu(), t, attn, prefix="backbone.", dropout=stream)
+    BR.masked_ce(al.float(), ids, ind.cpu(), attn).backward()
     # corruption is bit-exact against the reference formula on the same uniforms
     sched = BR.mask_schedule(T)
     want = (u < sched[t][:, None]) & (attn == 1) & (ids != 2) & (ids != 3)
@@ -76,8 +83,13 @@ def test_bpe_training_step_at_benchmark_shape(gpu_device, batch, p):
             continue
         e = rel(prm.grad.cpu(), gref)
         cos = torch.nn.functional.cosine_similarity(prm.grad.cpu().flatten(), gref.flatten(), dim=0).item()
+        e_ac = rel(ac_sd[k].grad.float(), gref)
         worst, worst_cos = max(worst, e), min(worst_cos, cos)
-        assert e < 5e-2 and cos > 0.998, (k, e, cos)
+        print(f"  {k:50s} rel {e:.4f} (bf16 autocast of the restatement: {e_ac:.4f}) cos {cos:.5f} |g| {gref.norm().item():.3e}")
+        # 2e-2 of the tensor's norm; the small q / k gradients may be as far off as bf16 autocast itself is on
+        # that tensor (measured: 3 % here where autocast loses 25 %), never more than 5e-2
+        assert e < max(2e-2, e_ac) and e < 5e-2, (k, e, e_ac)
+        assert cos > 0.999, (k, cos)
     assert n == 102
     print(f"C4 shape B={batch} p={p}: logits rel err {err:.2e}, loss {loss.item():.5f} vs {rloss.item():.5f}, "
           f"worst gradient rel err {worst:.3e}, worst cosine {worst_cos:.5f}")
