@@ -172,7 +172,8 @@ def test_embed(gpu_device):
     bad[2, 0] = -1
     tb = t.clone()
     tb[3] = T
-    _lib.check(_lib.lib().bd_embed(_lib.ptr(bad.to(dev)), _lib.ptr(tb.to(dev)), _lib.ptr(dv[2]), _lib.ptr(dv[3]),
+    bad_d, tb_d = bad.to(dev), tb.to(dev)
+    _lib.check(_lib.lib().bd_embed(_lib.ptr(bad_d), _lib.ptr(tb_d), _lib.ptr(dv[2]), _lib.ptr(dv[3]),
                                    _lib.ptr(dv[4]), _lib.ptr(x), B, L, d, V, 64, T, _s()), "embed")
     got = x.cpu().view(B, L, d)
     nan_rows = torch.isnan(got).all(-1)
