@@ -10,8 +10,13 @@ V = 39, T = 100), bf16 MFMA compute, random-init weights, synthetic vocabulary.
 
 Prints ONE JSON line on rank 0. With N > 1 every rank samples its own `--batch` sequences
 (weak scaling, no data-path collective; the global sequence index keys the random streams).
+Besides the headline it carries: `train` (the second half of the metric: the SMILES_BPE training
+step, with its own roofline, per-kernel table and CPU baseline), `configs` (the other sampling
+configurations: SELFIES, Group SELFIES and the 24-layer d = 1024, L = 512 stress backbone),
+`roofline` and `cpu_baseline` of the headline.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -27,14 +32,71 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 peak of MI355X
+HBM_PEAK_GBPS = 8000.0
+
+# kernel families of the library's event profiler (bd_prof_read_kind): name, unit of the work figure
+KINDS = {0: ("gemm_bf16_kernel (tiled GEMM: vocabulary head, projections, data gradients)", "flop"),
+         1: ("gemm_panel_kernel (row-panel projection with fused LayerNorm)", "flop"),
+         2: ("ffn_fused_kernel (LayerNorm + fc1 + GELU + fc2 + residual)", "flop"),
+         3: ("attn_block_kernel (LayerNorm + QKV + attention + out-proj + residual)", "flop"),
+         4: ("backbone_mega_kernel (whole forward: embeddings, all layers' attention + feed-forward phases, final LayerNorm)", "flop"),
+         5: ("wgrad_dma_kernel (weight-gradient GEMMs with bias sums)", "flop"),
+         6: ("attn_fwd_kernel (stand-alone attention forward)", "flop"),
+         7: ("attn_bwd_dq_kernel + attn_bwd_dkv_kernel (attention backward)", "flop"),
+         8: ("layernorm_kernel / layernorm_bwd_kernel", "byte"),
+         9: ("ce_fwd_kernel / ce_bwd_kernel (masked cross-entropy)", "byte"),
+         10: ("embed / embed_bwd / corrupt / dropout / cast kernels", "byte"),
+         11: ("sumsq / adamw / multi_cast kernels (clip, AdamW, bf16 weight refresh)", "byte"),
+         12: ("sample_step_kernel / fixup_kernel (reverse step and repairs)", "byte")}
 
 
 def fwd_flops_per_token(d, n_layers, ffn, L, V):
     return 2 * n_layers * (4 * d * d + 2 * d * ffn) + 4 * n_layers * L * d + 2 * d * V
 
 
+def prof_reset(lib):
+    lib.bd_prof_enable(1)
+    lib.bd_prof_read(None, None, None, 1)
+
+
+def prof_table(lib, wall_ms):
+    """Per-family launches / average duration / rate since the last reset (HIP events recorded by the library on
+    the launch stream around each entry point's launches)."""
+    out = {}
+    for kind, (name, unit) in KINDS.items():
+        n_k, ms_k, w_k = C.c_longlong(0), C.c_double(0.0), C.c_double(0.0)
+        lib.bd_prof_read_kind(kind, C.byref(n_k), C.byref(ms_k), C.byref(w_k), 1)
+        if not n_k.value:
+            continue
+        ent = {"kernel": name, "launches": n_k.value, "avg_launch_ms": ms_k.value / n_k.value, "total_ms": ms_k.value,
+               "share_of_timed_region": ms_k.value / wall_ms if wall_ms else None}
+        rate = w_k.value / (ms_k.value * 1e-3) if ms_k.value > 0 else 0.0
+        if unit == "flop":
+            ent.update(bound="mfma", tflops=rate / 1e12, frac=rate / 1e12 / MFMA_BF16_PEAK_TFLOPS, work_per_launch=w_k.value / n_k.value)
+        else:
+            ent.update(bound="hbm", gbps=rate / 1e9, frac=rate / 1e9 / HBM_PEAK_GBPS, work_per_launch=w_k.value / n_k.value)
+        out[kind] = ent
+    lib.bd_prof_enable(0)
+    return out
+
+
+def roofline_of(table, traffic=None, traffic_src=None):
+    dom = max(table, key=lambda k: table[k]["total_ms"])
+    e = table[dom]
+    mfma = e["bound"] == "mfma"
+    return {"bound": e["bound"], "kernel": e["kernel"], "achieved": e["tflops"] if mfma else e["gbps"],
+            "peak": MFMA_BF16_PEAK_TFLOPS if mfma else HBM_PEAK_GBPS, "unit": "TFLOP/s" if mfma else "GB/s",
+            "frac": e["frac"], "traffic": traffic, "traffic_source": traffic_src, "launches": e["launches"],
+            "avg_launch_ms": e["avg_launch_ms"], ("flops_per_launch" if mfma else "bytes_per_launch"): e["work_per_launch"],
+            "share_of_timed_region": e["share_of_timed_region"]}
+
+
+def named(table):
+    return {v["kernel"].split(" ")[0]: {k: x for k, x in v.items() if k != "kernel"} for v in table.values()}
+
+
 def cpu_baseline(sd, cfg, sampler, L, T, n_seq, threads):
-    """Oracle port of the same workload on the host cores, bounded sample."""
+    """Oracle port of the same workload on the host cores: BASELINE configuration 1 when n_seq = 256."""
     from oracle import cpu_baseline as CB
     from oracle import sampler_ref as ora
     torch.set_num_threads(threads)
@@ -43,24 +105,39 @@ def cpu_baseline(sd, cfg, sampler, L, T, n_seq, threads):
     _, t_net, t_step = CB.sample_smiles(sd, cfg, tb, n_seq, L, T, seed=1)
     dt = time.perf_counter() - t0
     return {"value": n_seq / dt, "unit": "sequences/s", "cores": threads, "kind": "port",
-            "sample": f"{n_seq} sequences x {T} steps, L={L}, fp32 PyTorch denoiser + C sampling oracle, "
-                      f"{dt:.1f} s ({t_net:.1f} s denoiser, {t_step:.1f} s sampling loop)"}
+            "sample": f"{n_seq} sequences in one batch x {T} steps, L={L}, constraints on, fp32 PyTorch denoiser + C sampling "
+                      f"oracle, {dt:.1f} s ({t_net:.1f} s denoiser, {t_step:.1f} s sampling loop)"}
 
 
-def train_bench(dev, rank, world, steps, warmup, batch=256, L=128):
+def bpe_batch(batch, L, V, seed):
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    lens = np.clip(np.round(rs.normal(38.5, 15.0, size=batch)), 12, L).astype(np.int64)
+    ids = rs.randint(5, V, size=(batch, L)).astype(np.int64)
+    attn = (np.arange(L)[None] < lens[:, None]).astype(np.int64)
+    ids[attn == 0] = 0
+    ids[:, 0] = 2
+    ids[np.arange(batch), lens - 1] = 3
+    return ids, attn
+
+
+def train_bench(dev, rank, world, steps, warmup, cpu_steps, threads, batch=256, L=128):
     """Second headline number: non-pad tokens/s of the SMILES_BPE training step (V = 803, T = 50,
     per-rank batch 256, L = 128 padded, dropout 0.1 on, AdamW lr 3e-4 wd 0.01, clip 1.0; one gradient-bucket
     all-reduce per step when world > 1)."""
-    import numpy as np
+    from bidiff import _lib
     from bidiff.model.backbone import DiffusionBackbone
     from bidiff.model.diffusion import DiscreteMaskingDiffusion
     from bidiff.training.optimizer import FlatAdamW
     from bidiff.parallel import allreduce_mean_
     V, T = 803, 50
+    cfg = dict(vocab_size=V, hidden_size=384, num_layers=6, num_heads=3, ffn_hidden_size=1536,
+               max_position_embeddings=256, num_diffusion_steps=T, dropout=0.1, pad_token_id=0)
     torch.manual_seed(42)
-    bb = DiffusionBackbone(V, 384, 6, 3, 1536, 256, T, 0.1, 0)
-    model = DiscreteMaskingDiffusion(bb, num_steps=T, mask_token_id=1, pad_token_id=0, bos_token_id=2,
-                                     eos_token_id=3).to(dev).train()
+    bb = DiffusionBackbone(**cfg)
+    model = DiscreteMaskingDiffusion(bb, num_steps=T, mask_token_id=1, pad_token_id=0, bos_token_id=2, eos_token_id=3)
+    sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
+    model = model.to(dev).train()
     model.corruption_rng = "philox"
     staged = world > 1 and dist.get_backend() == "gloo"      # rehearsal on one device: exchange through the host
     if world > 1:
@@ -72,13 +149,7 @@ def train_bench(dev, rank, world, steps, warmup, batch=256, L=128):
             else:
                 dist.broadcast(t_.data, src=0)
     opt = FlatAdamW(model.parameters(), lr=3e-4, weight_decay=0.01)
-    rs = np.random.RandomState(1 + rank)
-    lens = np.clip(np.round(rs.normal(38.5, 15.0, size=batch)), 12, L).astype(np.int64)
-    ids = rs.randint(5, V, size=(batch, L)).astype(np.int64)
-    attn = (np.arange(L)[None] < lens[:, None]).astype(np.int64)
-    ids[attn == 0] = 0
-    ids[:, 0] = 2
-    ids[np.arange(batch), lens - 1] = 3
+    ids, attn = bpe_batch(batch, L, V, 1 + rank)
     ids_d, attn_d = torch.from_numpy(ids).to(dev), torch.from_numpy(attn).to(dev)
     tokens = int(attn.sum())
 
@@ -114,13 +185,127 @@ def train_bench(dev, rank, world, steps, warmup, batch=256, L=128):
         dist.all_reduce(tok, op=dist.ReduceOp.SUM)
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
     el = float(tm.item())
-    return {"metric": "train non-pad tokens/sec (Bi_Diffusion_SMILES_BPE training step)",
-            "value": float(tok.item()) * steps / el, "unit": "non-pad tokens/s",
-            "padded_tokens_per_s": world * batch * L * steps / el, "ms_per_step": 1e3 * el / steps,
-            "steps": steps, "warmup": warmup, "final_loss": float(loss.item()),
-            "config": {"workload": f"SMILES_BPE small backbone (V=803, T=50), per-GPU batch {batch}, L={L} padded, "
-                                   f"{tokens} non-pad tokens per rank-batch, dropout 0.1 at all four sites (in-kernel Philox), AdamW + clip 1.0",
-                       "parallelism": f"dp{world}, one flat-gradient all-reduce per step"}}
+    final_loss = float(loss.item())
+    ms_step = 1e3 * el / steps
+    # per-kernel table: a few more steps with the library's events on (they cost a few microseconds per launch, so
+    # these steps are not the timed ones)
+    lib = _lib.lib()
+    n_prof = max(2, min(5, steps))
+    torch.cuda.synchronize()
+    prof_reset(lib)
+    t0 = time.perf_counter()
+    for _ in range(n_prof):
+        step()
+    torch.cuda.synchronize()
+    table = prof_table(lib, 1e3 * (time.perf_counter() - t0))
+    flops_step = 3.0 * fwd_flops_per_token(384, 6, 1536, L, V) * batch * L       # forward + 2x backward, padded rows included
+    tfl = flops_step / (ms_step * 1e-3) / 1e12
+    res = {"metric": "train non-pad tokens/sec (Bi_Diffusion_SMILES_BPE training step)",
+           "value": float(tok.item()) * steps / el, "unit": "non-pad tokens/s",
+           "padded_tokens_per_s": world * batch * L * steps / el, "ms_per_step": ms_step,
+           "steps": steps, "warmup": warmup, "final_loss": final_loss, "dtype": "bf16",
+           "config": {"workload": f"SMILES_BPE small backbone (V=803, T=50), per-GPU batch {batch}, L={L} padded, "
+                                  f"{tokens} non-pad tokens per rank-batch, dropout 0.1 at all four sites (in-kernel Philox), AdamW + clip 1.0",
+                      "parallelism": f"dp{world}, one flat-gradient all-reduce per step"},
+           # whole step against the MFMA roofline: 3 x forward flops of every padded token / step time
+           "roofline": {"bound": "mfma", "kernel": "whole training step (forward + backward + clip + AdamW)",
+                        "achieved": tfl, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / MFMA_BF16_PEAK_TFLOPS,
+                        "flops_per_step": flops_step, "traffic": None,
+                        "dominant_kernel": roofline_of(table) if table else None},
+           "kernels": named(table), "profiled_steps": n_prof}
+    if cpu_steps > 0 and world == 1 and rank == 0:
+        from oracle import cpu_baseline as CB
+        torch.set_num_threads(threads)
+        sec, closs = CB.train_steps_bpe(sd_cpu, cfg, torch.from_numpy(ids), torch.from_numpy(attn), T, cpu_steps)
+        res["cpu_baseline"] = {"value": tokens / sec, "unit": "non-pad tokens/s", "cores": threads, "kind": "port",
+                               "sample": f"{cpu_steps} timed steps (1 warm-up) of the same batch ({batch} x {L}, {tokens} non-pad tokens): "
+                                         f"fp32 PyTorch restatement of corruption + denoiser + masked CE, autograd, "
+                                         f"clip_grad_norm_ + torch AdamW, dropout off; {sec:.2f} s per step"}
+    return res
+
+
+def variant_bench(dev, variant, B, L, T, world, rank):
+    """One more sampling configuration on the small backbone: SELFIES (V = 43) or Group SELFIES (V = 233)."""
+    from bidiff import _lib
+    from bidiff.model.backbone import DiffusionBackbone
+    from bidiff.model.diffusion import DiscreteMaskingDiffusion
+    from bidiff.utils import synthetic
+    if variant == "selfies":
+        from bidiff.sampling.selfies_sampler import ConstrainedSampler
+        tok = synthetic.selfies_tokenizer()
+    else:
+        from bidiff.sampling.group_selfies_sampler import ConstrainedSampler
+        tok = synthetic.group_selfies_tokenizer()
+    torch.manual_seed(42)
+    bb = DiffusionBackbone(tok.vocab_size, 384, 6, 3, 1536, max(256, L), T, 0.1, tok.pad_token_id)
+    model = DiscreteMaskingDiffusion(bb, num_steps=T, mask_token_id=tok.mask_token_id, pad_token_id=tok.pad_token_id,
+                                     bos_token_id=tok.bos_token_id, eos_token_id=tok.eos_token_id).to(dev).eval()
+    smp = ConstrainedSampler(model, tok, num_steps=T, temperature=1.0, use_constraints=True, device=str(dev))
+    smp._core.seed = 7
+    lib = _lib.lib()
+
+    def run(i):
+        ids = torch.full((B, L), tok.mask_token_id, dtype=torch.long, device=dev)
+        ids[:, 0] = tok.bos_token_id
+        ids[:, -1] = tok.eos_token_id
+        has_eos = torch.ones(B, dtype=torch.uint8, device=dev) if variant == "selfies" else None
+        return smp._core.run(ids, torch.ones_like(ids), None, seq_offset=(i * world + rank) * B, has_eos=has_eos)
+    run(0)
+    torch.cuda.synchronize()
+    prof_reset(lib)
+    t0 = time.perf_counter()
+    out = run(1)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    table = prof_table(lib, 1e3 * el)
+    assert (out != tok.mask_token_id).all()
+    fl = fwd_flops_per_token(384, 6, 1536, L, tok.vocab_size) * L * T * B
+    return {"metric": f"generated sequences/sec (Bi_Diffusion_{'SELFIES' if variant == 'selfies' else 'Group_SELFIES'} reverse sampling)",
+            "value": B / el, "unit": "sequences/s (per GPU)", "ms_per_batch": 1e3 * el,
+            "config": {"workload": f"small backbone, V={tok.vocab_size}, batch {B}, L={L}, T={T}, constraints on"},
+            "whole_path_tflops": fl / el / 1e12, "roofline": roofline_of(table), "kernels": named(table)}
+
+
+def c5_bench(dev, B, L, T):
+    """The stress configuration: 24 layers, d = 1024, ffn 4096, 8 heads of 128, L = 512."""
+    from bidiff import _lib
+    from bidiff.model.backbone import DiffusionBackbone
+    from bidiff.model.diffusion import DiscreteMaskingDiffusion
+    from bidiff.sampling.sampler import ConstrainedSampler
+    from bidiff.utils import synthetic
+    tok = synthetic.smiles_tokenizer()
+    torch.manual_seed(42)
+    bb = DiffusionBackbone(tok.vocab_size, 1024, 24, 8, 4096, L, T, 0.1, tok.pad_token_id)
+    model = DiscreteMaskingDiffusion(bb, num_steps=T, mask_token_id=tok.mask_token_id, pad_token_id=tok.pad_token_id,
+                                     bos_token_id=tok.bos_token_id, eos_token_id=tok.eos_token_id).to(dev).eval()
+    smp = ConstrainedSampler(model, tok, num_steps=T, temperature=1.0, use_constraints=True, device=str(dev))
+    smp._core.seed = 11
+    lib = _lib.lib()
+    ids0, am0, fm0 = smp.initial_state(B, L)
+    t_ = torch.full((B,), T, device=dev, dtype=torch.long)
+    with torch.no_grad():
+        bb.get_hidden_states(ids0, t_, am0)                 # warm-up forward (weight packing)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = smp._core.run(ids0, am0, fm0, seq_offset=0)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    assert (out != tok.mask_token_id).all()
+    # per-kernel table from three more forwards with the library's events on (about 170 launches per forward:
+    # the events are kept out of the timed loop)
+    prof_reset(lib)
+    t1 = time.perf_counter()
+    with torch.no_grad():
+        for _ in range(3):
+            bb.get_hidden_states(out, t_, am0)
+    torch.cuda.synchronize()
+    table = prof_table(lib, 1e3 * (time.perf_counter() - t1))
+    fl = fwd_flops_per_token(1024, 24, 4096, L, tok.vocab_size) * L * T * B
+    return {"metric": "generated sequences/sec (scaled-up backbone, 24 layers, d=1024, L=512)",
+            "value": B / el, "unit": "sequences/s (per GPU)", "ms_per_batch": 1e3 * el, "ms_per_forward": 1e3 * el / T,
+            "config": {"workload": f"24 layers, d=1024, ffn 4096, 8 heads, V={tok.vocab_size}, batch {B}, L={L}, T={T}, constraints on"},
+            "whole_path_tflops": fl / el / 1e12, "whole_path_frac": fl / el / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+            "roofline": roofline_of(table), "kernels": named(table)}
 
 
 def main():
@@ -131,9 +316,13 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--seq-len", type=int, default=128)
     ap.add_argument("--diffusion-steps", type=int, default=100)
-    ap.add_argument("--cpu-seqs", type=int, default=64, help="sequences in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-seqs", type=int, default=256,
+                    help="sequences in the CPU baseline (256 = BASELINE configuration 1; 0 = skip)")
+    ap.add_argument("--cpu-train-steps", type=int, default=2, help="timed CPU training steps (0 = skip)")
     ap.add_argument("--no-constraints", action="store_true")
     ap.add_argument("--train-steps", type=int, default=20, help="timed training steps (0 = skip the training leg)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the SELFIES / Group SELFIES / stress-backbone records")
+    ap.add_argument("--c5-batch", type=int, default=128)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -186,27 +375,14 @@ def main():
     for i in range(args.warmup):
         run_batch(i)
     lib = _lib.lib()
-    lib.bd_prof_enable(1)
-    lib.bd_prof_read(None, None, None, 1)
+    prof_reset(lib)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         ids = run_batch(args.warmup + i)
     barrier()
     elapsed = time.perf_counter() - t0
-    import ctypes as C
-    kinds = {0: "gemm_bf16_kernel (tiled GEMM: vocabulary head and unfused projections)",
-             1: "gemm_panel_kernel (row-panel projection with fused LayerNorm)",
-             2: "ffn_fused_kernel (LayerNorm + fc1 + GELU + fc2 + residual)",
-             3: "attn_block_kernel (LayerNorm + QKV + attention + out-proj + residual)",
-             4: "backbone_mega_kernel (whole forward: embeddings, all layers' attention + feed-forward phases, final LayerNorm)"}
-    prof = {}
-    for kind in kinds:
-        n_k, ms_k, fl_k = C.c_longlong(0), C.c_double(0.0), C.c_double(0.0)
-        lib.bd_prof_read_kind(kind, C.byref(n_k), C.byref(ms_k), C.byref(fl_k), 1)
-        if n_k.value:
-            prof[kind] = (n_k.value, ms_k.value, fl_k.value)
-    lib.bd_prof_enable(0)
+    table = prof_table(lib, 1e3 * elapsed)
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -214,36 +390,45 @@ def main():
 
     # strings are decoded on the host outside the timed region (host tokenizer work)
     assert (ids != tok.mask_token_id).all()
+    del ids
+    torch.cuda.empty_cache()
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
     train = None
     if args.train_steps > 0:
-        del ids
-        torch.cuda.empty_cache()
         try:
-            train = train_bench(dev, rank, world, args.train_steps, 5)
+            train = train_bench(dev, rank, world, args.train_steps, 5, args.cpu_train_steps, threads)
         except Exception as exc:      # the sampling line (the headline metric) is still reported
             train = {"error": f"{type(exc).__name__}: {exc}"}
+    configs = None
+    if not args.no_configs:
+        configs = {}
+        for name, fn in (("selfies", lambda: variant_bench(dev, "selfies", B, L, T, world, rank)),
+                         ("group_selfies", lambda: variant_bench(dev, "group", B, L, T, world, rank)),
+                         ("c5_24L_d1024_L512", lambda: c5_bench(dev, args.c5_batch, 512, T))):
+            torch.cuda.empty_cache()
+            try:
+                configs[name] = fn()
+            except Exception as exc:
+                configs[name] = {"error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
         total_seqs = world * B * args.steps
         value = total_seqs / elapsed
         flops_seq = fwd_flops_per_token(384, 6, 1536, L, tok.vocab_size) * L * T
-        # roofline of the kernel the timed region spends most of its time in (HIP events recorded by the
-        # library on the launch stream around every launch of that kernel)
-        dom = max(prof, key=lambda k: prof[k][1])
-        n_dom, ms_dom, fl_dom = prof[dom]
-        dom_tflops = fl_dom / (ms_dom * 1e-3) / 1e12
-        step_ms = 1e3 * elapsed
-        # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process, so
-        # the figure comes from the committed rocprofv3 --pmc passes (profiles/r1_pmc_traffic.json)
+        # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process,
+        # so the figure comes from the committed rocprofv3 --pmc passes (profiles/*_pmc_traffic.json)
         traffic, traffic_src = None, None
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")) as fh:
-                tj = json.load(fh)
-            ent = tj["kernels"].get(kinds[dom].split(" ")[0])
-            if ent and B * L == 4096 * 128:
-                traffic, traffic_src = ent["traffic_bytes"], tj["source"]
-        except (OSError, ValueError, KeyError):
-            pass
+        dom = max(table, key=lambda k: table[k]["total_ms"])
+        for fname in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", fname)) as fh:
+                    tj = json.load(fh)
+                ent = tj["kernels"].get(KINDS[dom][0].split(" ")[0])
+                if ent and B * L == 4096 * 128:
+                    traffic, traffic_src = ent["traffic_bytes"], tj["source"]
+                    break
+            except (OSError, ValueError, KeyError):
+                pass
         out = {
             "metric": "generated sequences/sec (Bi_Diffusion_SMILES reverse sampling, 100 steps, L=128)",
             "value": value, "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -254,20 +439,15 @@ def main():
                                    f"{'off' if args.no_constraints else 'on'}, logits at chosen rows only (t>1), "
                                    f"full logits at t=1, on-device repairs",
                        "batch_per_gpu": B, "seq_len": L, "diffusion_steps": T, "sharding": f"{world} x independent batches"},
-            "roofline": {"bound": "mfma", "kernel": kinds[dom],
-                         "achieved": dom_tflops, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": dom_tflops / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "launches": n_dom, "avg_launch_ms": ms_dom / n_dom, "flops_per_launch": fl_dom / n_dom,
-                         "share_of_timed_region": ms_dom / step_ms},
-            "kernels": {kinds[k].split(" ")[0]: {"launches": v[0], "avg_launch_ms": v[1] / v[0],
-                                                 "tflops": v[2] / (v[1] * 1e-3) / 1e12, "share_of_timed_region": v[1] / step_ms}
-                        for k, v in prof.items()},
+            "roofline": roofline_of(table, traffic, traffic_src),
+            "kernels": named(table),
             "whole_path_tflops": value / world * flops_seq / 1e12,
         }
         if train is not None:
             out["train"] = train
+        if configs is not None:
+            out["configs"] = configs
         if args.cpu_seqs > 0 and world == 1:
-            threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
             out["cpu_baseline"] = cpu_baseline(sd_cpu, cfg, smp, L, T, args.cpu_seqs, threads)
         print(json.dumps(out))
     if world > 1:

@@ -18,6 +18,7 @@
 // second product in natural key order.
 #include "bd_common.h"
 #include "bd_drop.h"
+#include "bd_prof.h"
 
 namespace {
 
@@ -264,6 +265,7 @@ extern "C" int bd_attention_fwd_drop(const void* qkv, const unsigned char* keyma
   bd_drop_args da;
   BD_REQUIRE(bd_drop_make(drop, site, &da), "bd_attention_fwd: dropout p=%g outside [0, 1)", (double)drop->p);
   BD_REQUIRE(da.thr == 0u || (long long)B * H * L < (1ll << 32), "bd_attention_fwd: dropout needs B*H*L < 2^32");
+  bd_prof_scope prof(stream, 4.0 * (double)B * H * L * L * head_dim, BD_PROF_ATTN_FWD);
   const float scale = 1.0f / sqrtf((float)head_dim);
   hipStream_t s = (hipStream_t)stream;
   switch (head_dim) {

@@ -2,6 +2,7 @@
 #include "bd_common.h"
 #include "bd_rng.h"
 #include "bd_drop.h"
+#include "bd_prof.h"
 
 namespace {
 
@@ -340,6 +341,7 @@ static int dropout_launch(const float* x, void* out, int M, int N, const bd_drop
   BD_REQUIRE(M > 0 && N > 0 && N % 4 == 0, "bd_dropout: bad shape M=%d N=%d", M, N);
   bd_drop_args da;
   BD_REQUIRE(bd_drop_make(drop, site, &da), "bd_dropout: p=%g outside [0, 1)", (double)drop->p);
+  bd_prof_scope prof(stream, (double)M * N * (bf16 ? 6.0 : 8.0), BD_PROF_EMBED);
   const long long n4 = (long long)M * (N / 4);
   const unsigned grid = (unsigned)((n4 + 255) / 256 < 65536 ? (n4 + 255) / 256 : 65536);
   if (bf16) hipLaunchKernelGGL(dropout_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, out, n4, N / 4, da);
@@ -369,6 +371,7 @@ extern "C" int bd_embed_drop(const long long* ids, const long long* timesteps, c
   BD_REQUIRE(B > 0 && L > 0 && d > 0 && d % 4 == 0, "bd_embed: bad shape B=%d L=%d d=%d", B, L, d);
   const long long M = (long long)B * L;
   BD_REQUIRE(M < (1ll << 31), "bd_embed: too many tokens");
+  bd_prof_scope prof(stream, (double)M * (d * 4.0 + 8.0), BD_PROF_EMBED);
   hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ids,
                      timesteps, tok_emb, pos_emb, time_emb, x, (int)M, L, d, vocab, n_timesteps, da);
   return bd_check_launch("bd_embed");
@@ -378,6 +381,7 @@ extern "C" int bd_layernorm(const float* x, const float* gamma, const float* bet
                             float* out_f32, float* stats, int M, int d, float eps, void* stream) {
   BD_REQUIRE(x && gamma && beta && (out_bf16 || out_f32), "bd_layernorm: null operand");
   BD_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 4096, "bd_layernorm: bad shape M=%d d=%d", M, d);
+  bd_prof_scope prof(stream, (double)M * d * (4.0 + (out_bf16 ? 2.0 : 0.0) + (out_f32 ? 4.0 : 0.0)), BD_PROF_LN);
   dim3 grid((M + 3) / 4), block(256);
   hipStream_t s = (hipStream_t)stream;
   unsigned short* ob = (unsigned short*)out_bf16;
@@ -402,6 +406,7 @@ extern "C" int bd_corrupt(const long long* ids, const long long* attention_mask,
                           unsigned long long seed, long long seq_offset, void* stream) {
   BD_REQUIRE(ids && timesteps && schedule && noisy_ids && mask_indicator, "bd_corrupt: null operand");
   BD_REQUIRE(B >= 0 && L >= 0 && schedule_len > 0, "bd_corrupt: bad shape");
+  bd_prof_scope prof(stream, (double)B * L * (uniforms ? 29.0 : 25.0), BD_PROF_EMBED);
   const long long n = (long long)B * L;
   if (n == 0) return BD_OK;
   const bool aligned = ((((uintptr_t)ids | (uintptr_t)noisy_ids | (uintptr_t)attention_mask | (uintptr_t)uniforms) & 15u) == 0u) &&

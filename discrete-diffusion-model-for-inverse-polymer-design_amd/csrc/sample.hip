@@ -16,6 +16,7 @@
 #include "bd_common.h"
 #include "bd_rng.h"
 #include "bidiff.h"
+#include "bd_prof.h"
 
 namespace {
 
@@ -695,6 +696,8 @@ extern "C" int bd_sample_step(const bd_step_args* a, void* stream) {
   if (p.B == 0) return BD_OK;
   const size_t lds = smem_bytes(p.L, p.V, p.d, p.R > 0 ? p.R : 1);
   BD_REQUIRE(lds <= 64 * 1024, "bd_sample_step: working set of %zu bytes per sequence exceeds LDS", lds);
+  // ids in and out, fixed mask, and (hidden mode) about one hidden row and its result per chosen position
+  bd_prof_scope prof(stream, (double)p.B * (17.0 * p.L + (p.hidden ? 2.0 * p.d + 8.0 : 4.0 * p.L * p.V)), BD_PROF_SAMPLE);
   hipLaunchKernelGGL(sample_step_kernel, dim3(p.B), dim3(64), lds, (hipStream_t)stream, p);
   return bd_check_launch("bd_sample_step");
 }
@@ -711,6 +714,7 @@ extern "C" int bd_sample_fixup(const bd_fix_args* a, void* stream) {
              "bd_sample_fixup: SMILES repairs need the token tables");
   BD_REQUIRE(p.n_excl >= 0 && p.n_excl <= 8, "bd_sample_fixup: too many excluded ids");
   if (p.B == 0) return BD_OK;
+  bd_prof_scope prof(stream, (double)p.B * 16.0 * p.L, BD_PROF_SAMPLE);
   hipLaunchKernelGGL(fixup_kernel, dim3(p.B), dim3(64), 0, (hipStream_t)stream, p);
   return bd_check_launch("bd_sample_fixup");
 }

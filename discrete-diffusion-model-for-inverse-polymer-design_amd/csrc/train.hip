@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include "bd_drop.h"
 #include "bidiff.h"
+#include "bd_prof.h"
 
 namespace {
 
@@ -1041,6 +1042,7 @@ extern "C" int bd_masked_ce_fwd(const float* logits, const long long* targets, c
   BD_REQUIRE(logits && targets && indicator && lse && sums, "bd_masked_ce_fwd: null operand");
   BD_REQUIRE(M >= 0 && V > 0, "bd_masked_ce_fwd: bad shape");
   if (M == 0) return BD_OK;
+  bd_prof_scope prof(stream, (double)M * V * 4.0, BD_PROF_CE);
   hipLaunchKernelGGL(ce_fwd_kernel, dim3((M + CE_ROWS - 1) / CE_ROWS), dim3(256), 0, (hipStream_t)stream, logits, targets,
                      indicator, attention_mask, lse, sums, M, V);
   return bd_check_launch("bd_masked_ce_fwd");
@@ -1052,6 +1054,7 @@ extern "C" int bd_masked_ce_bwd(const float* logits, const long long* targets, c
   BD_REQUIRE(logits && targets && indicator && lse && sums && grad_out && dlogits, "bd_masked_ce_bwd: null operand");
   BD_REQUIRE(M >= 0 && V > 0, "bd_masked_ce_bwd: bad shape");
   if (M == 0) return BD_OK;
+  bd_prof_scope prof(stream, (double)M * V * 8.0, BD_PROF_CE);
   hipLaunchKernelGGL(ce_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, targets,
                      indicator, attention_mask, lse, sums, grad_out, dlogits, M, V);
   return bd_check_launch("bd_masked_ce_bwd");
@@ -1071,6 +1074,7 @@ extern "C" int bd_layernorm_bwd_cast(const void* dy_bf16, const float* x, const 
   const unsigned short* dy = (const unsigned short*)dy_bf16;
   unsigned short* ob = (unsigned short*)dx_bf16;
   const int nv = (d / 4 + 63) / 64;
+  bd_prof_scope prof(stream, (double)M * d * (2.0 + 4.0 + 4.0 + 4.0 + (dx_bf16 ? 2.0 : 0.0)), BD_PROF_LN);
 #define BD_LNB(NV) hipLaunchKernelGGL(layernorm_bwd_kernel<NV>, grid, block, lds, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d, ob, da)
   if (nv <= 1) BD_LNB(1);
   else if (nv <= 2) BD_LNB(2);
@@ -1119,6 +1123,7 @@ extern "C" int bd_gemm_wgrad_segments(const void* dY, int ldy, const void* X, in
   for (int i = 0; i < n_seg; ++i) BD_REQUIRE(dW[i] != nullptr, "bd_gemm_wgrad: null destination %d", i);
   hipStream_t s = (hipStream_t)stream;
   static int use_dma = getenv("BD_WGRAD_DMA") ? atoi(getenv("BD_WGRAD_DMA")) : 1;
+  bd_prof_scope prof(stream, 2.0 * (double)M * N * K, BD_PROF_WGRAD);
   if (M % 32 == 0 && use_dma) {
     static int ncu = 0;
     if (!ncu) {
@@ -1186,6 +1191,7 @@ extern "C" int bd_attention_bwd_drop(const void* qkv, const unsigned char* keyma
   bd_drop_args da;
   BD_REQUIRE(bd_drop_make(drop, site, &da), "bd_attention_bwd: dropout p=%g outside [0, 1)", (double)drop->p);
   BD_REQUIRE(da.thr == 0u || (long long)B * H * L < (1ll << 32), "bd_attention_bwd: dropout needs B*H*L < 2^32");
+  bd_prof_scope prof(stream, 10.0 * (double)B * H * L * L * head_dim, BD_PROF_ATTN_BWD);   // S, dP twice; dQ, dK, dV
   const float scale = 1.0f / sqrtf((float)head_dim);
   dim3 grid((L + 63) / 64, H, B), block(256);
   hipStream_t s = (hipStream_t)stream;
@@ -1218,6 +1224,7 @@ extern "C" int bd_embed_bwd(const float* dx, const long long* ids, const long lo
   BD_REQUIRE(vocab > 0 && n_timesteps > 0, "bd_embed_bwd: empty table");
   BD_REQUIRE(L <= max_pos, "bd_embed_bwd: sequence length %d exceeds max_position_embeddings %d", L, max_pos);
   BD_REQUIRE(B > 0 && L > 0 && L <= EB_MAXL && d > 0, "bd_embed_bwd: bad shape B=%d L=%d d=%d", B, L, d);
+  bd_prof_scope prof(stream, 2.0 * (double)B * L * d * 4.0, BD_PROF_EMBED);
   hipLaunchKernelGGL(embed_bwd_seq_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, dx, ids, timesteps, dtok,
                      dtime, L, d, pad_id, vocab, n_timesteps);
   // enough workgroups to fill the chip: the batch is cut into slices when there are few positions
@@ -1229,6 +1236,7 @@ extern "C" int bd_embed_bwd(const float* dx, const long long* ids, const long lo
 
 extern "C" int bd_sumsq_f32(const float* x, long long n, float* out, void* stream) {
   BD_REQUIRE(x && out && n >= 0, "bd_sumsq_f32: bad argument");
+  bd_prof_scope prof(stream, (double)n * 4.0, BD_PROF_OPT);
   if (n == 0) return BD_OK;
   long long blocks = (n + 4095) / 4096;
   blocks = blocks > 512 ? 512 : blocks;     // one same-address atomic per workgroup: keep them few
@@ -1242,6 +1250,7 @@ extern "C" int bd_adamw_step(float* params, const float* grads, float* exp_avg, 
                              float max_norm, void* stream) {
   BD_REQUIRE(params && grads && exp_avg && exp_avg_sq && n >= 0, "bd_adamw_step: bad argument");
   BD_REQUIRE(bias_correction1 > 0.f && bias_correction2_sqrt > 0.f, "bd_adamw_step: bias corrections must be > 0");
+  bd_prof_scope prof(stream, (double)n * 28.0, BD_PROF_OPT);
   if (n == 0) return BD_OK;
   long long blocks = (n + 255) / 256;
   blocks = blocks > 4096 ? 4096 : blocks;
@@ -1278,6 +1287,7 @@ extern "C" int bd_muon_step(float* params, const float* grads, float* momentum_b
              "bd_muon_step: %d matrices of %d x %d (sizes must be multiples of 128)", nb, rows, cols);
   BD_REQUIRE(workspace_bytes >= bd_muon_workspace_bytes(nb, rows, cols), "bd_muon_step: workspace too small");
   BD_REQUIRE(momentum >= 0.f && momentum <= 1.f, "bd_muon_step: momentum=%g", (double)momentum);
+  bd_prof_scope prof(stream, (double)nb * rows * cols * 28.0, BD_PROF_OPT);
   hipStream_t s = (hipStream_t)stream;
   const int r = rows < cols ? rows : cols, c = rows < cols ? cols : rows;
   const long long n = (long long)rows * cols;
@@ -1315,6 +1325,7 @@ extern "C" int bd_multi_cast_bf16(const bd_cast_job* jobs_device, int n_jobs, in
   BD_REQUIRE(jobs_device && n_jobs > 0 && n_jobs <= 65535 && max_rows > 0 && max_cols > 0, "bd_multi_cast_bf16: bad argument");
   const long long tiles = (long long)((max_rows + 63) / 64) * ((max_cols + 63) / 64);
   BD_REQUIRE(tiles < (1ll << 31), "bd_multi_cast_bf16: job too large");
+  bd_prof_scope prof(stream, 0.0, BD_PROF_OPT);
   hipLaunchKernelGGL(multi_cast_kernel, dim3((unsigned)tiles, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_device);
   return bd_check_launch("bd_multi_cast_bf16");
 }

@@ -509,7 +509,10 @@ float bd_host_uniform_token(unsigned long long seed, uint32_t seq, uint32_t t, u
 int bd_prof_enable(int on);
 int bd_prof_read(long long* launches, double* total_ms, double* total_flops, int reset);
 /* Same, for one kernel family: 0 tiled GEMM, 1 row-panel GEMM, 2 fused feed-forward block,
- * 3 fused attention block, 4 whole-forward kernel; -1 = all families together. */
+ * 3 fused attention block, 4 whole-forward kernel, 5 weight-gradient GEMM, 6 attention forward,
+ * 7 attention backward; and, with algorithmic BYTES in place of flops, 8 LayerNorm forward / backward,
+ * 9 masked cross-entropy, 10 embedding / corruption / dropout / casts, 11 optimizer, 12 reverse step and
+ * repairs; -1 = all families together. */
 int bd_prof_read_kind(int kind, long long* launches, double* total_ms, double* total_flops, int reset);
 
 #ifdef __cplusplus

@@ -50,3 +50,30 @@ def sample_smiles(sd, cfg, tb, B, L, T, temperature=1.0, use_constraints=True, s
         ids = ora.sample_fixup(tb, ids, last)["ids"]
         t_step += time.perf_counter() - t0
     return ids, t_net, t_step
+
+
+def train_steps_bpe(sd, cfg, ids, attn, T, steps, warmup=1, lr=3e-4, weight_decay=0.01, max_norm=1.0, seed=0):
+    """The reference's training step restated on the CPU in fp32: corruption (diffusion.py:84-127), denoiser
+    forward, masked CE (:169-209), backward, clip_grad_norm_ and AdamW (trainer_backbone.py:414-457), dropout as
+    the identity. Returns (seconds per step over ``steps`` timed steps, last loss)."""
+    params = {k: torch.nn.Parameter(v.clone()) for k, v in sd.items() if v.dtype.is_floating_point and k != "mask_schedule"}
+    opt = torch.optim.AdamW(params.values(), lr=lr, weight_decay=weight_decay)
+    sched = BR.mask_schedule(T)
+    g = torch.Generator().manual_seed(seed)
+    B, L = ids.shape
+    el, loss = 0.0, None
+    for i in range(warmup + steps):
+        t0 = time.perf_counter()
+        t = torch.randint(1, T + 1, (B,), generator=g)
+        u = torch.rand(B, L, generator=g)
+        ind = (u < sched[t][:, None]) & (attn == 1) & (ids != 2) & (ids != 3)
+        noisy = torch.where(ind, torch.ones_like(ids), ids)
+        lg = BR.logits(params, cfg, noisy, t, attn, prefix="backbone.")
+        loss = BR.masked_ce(lg, ids, ind, attn)
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params.values(), max_norm)
+        opt.step()
+        if i >= warmup:
+            el += time.perf_counter() - t0
+    return el / max(steps, 1), float(loss.item())
