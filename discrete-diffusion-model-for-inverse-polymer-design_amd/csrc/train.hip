@@ -3,6 +3,7 @@
 // gradient norm and the fused AdamW update.
 #include "bd_common.h"
 #include <stdlib.h>
+#include <mutex>
 #include "bd_drop.h"
 #include "bidiff.h"
 #include "bd_prof.h"
@@ -1215,6 +1216,43 @@ extern "C" int bd_attention_bwd_drop(const void* qkv, const unsigned char* keyma
   }
 #undef BD_LAUNCH_BWD
   return bd_check_launch("bd_attention_bwd");
+}
+
+// ---- attention backward for callers that cannot allocate (HIP graph capture, tight serving loops): the
+// [B, H, L] fp32 row sums the two kernels exchange live in a file-scope device array instead of a caller
+// buffer. Each GPU holds its own copy of the array at its own address, looked up once per device.
+constexpr long long BD_STATIC_DELTA_FLOATS = 1ll << 22;      // 16 MiB per GPU, held until the process ends
+static __device__ __align__(256) float bd_static_delta[BD_STATIC_DELTA_FLOATS];
+constexpr int BD_STATIC_MAX_DEVICES = 64;
+static float* g_static_delta_ptr[BD_STATIC_MAX_DEVICES] = {};
+static std::mutex g_static_delta_mu;
+
+extern "C" long long bd_attention_bwd_static_capacity(void) { return BD_STATIC_DELTA_FLOATS; }
+
+extern "C" int bd_attention_bwd_static(const void* qkv, const unsigned char* keymask, const void* out, const void* dout,
+                                       const float* lse, void* dqkv, int B, int L, int H, int head_dim, void* stream) {
+  BD_REQUIRE(B > 0 && L > 0 && H > 0, "bd_attention_bwd_static: bad shape");
+  BD_REQUIRE((long long)B * H * L <= BD_STATIC_DELTA_FLOATS,
+             "bd_attention_bwd_static: B*H*L = %lld exceeds the built-in scratch of %lld entries (use bd_attention_bwd "
+             "with a caller buffer)", (long long)B * H * L, BD_STATIC_DELTA_FLOATS);
+  int dev = -1;
+  BD_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < BD_STATIC_MAX_DEVICES,
+             "bd_attention_bwd_static: no current device (or device index >= %d)", BD_STATIC_MAX_DEVICES);
+  float* delta = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_static_delta_mu);
+    if (g_static_delta_ptr[dev] == nullptr) {
+      void* p = nullptr;
+      const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(bd_static_delta));
+      if (e != hipSuccess || p == nullptr)
+        return bd_fail(BD_ERR_LAUNCH, "bd_attention_bwd_static: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
+      g_static_delta_ptr[dev] = (float*)p;
+    }
+    delta = g_static_delta_ptr[dev];
+  }
+  // every entry a kernel reads (queries 0..L-1 of each head) is written by the dq kernel of this call first:
+  // nothing of an earlier call's contents is consumed, so nothing has to be cleared
+  return bd_attention_bwd_drop(qkv, keymask, out, dout, lse, delta, dqkv, B, L, H, head_dim, nullptr, 0u, stream);
 }
 
 extern "C" int bd_embed_bwd(const float* dx, const long long* ids, const long long* timesteps, float* dtok,

@@ -337,6 +337,16 @@ int bd_attention_bwd(const void* qkv, const unsigned char* keymask, const void* 
                      const float* lse, float* delta, void* dqkv, int B, int L, int H, int head_dim,
                      void* stream);
 
+/* bd_attention_bwd without the scratch argument, for callers that cannot allocate device memory (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc). No counterpart in the reference. The
+ * [B, H, L] fp32 row sums live in a file-scope device array of bd_attention_bwd_static_capacity() = 2^22 entries
+ * (16 MiB, held per GPU until the process ends); a larger B*H*L is rejected with BD_ERR_ARG. The call allocates
+ * nothing (with the event profiler off). Calls that overlap on one GPU - other streams or threads - share that
+ * array and race; calls on one stream, one after another, are safe. */
+long long bd_attention_bwd_static_capacity(void);
+int bd_attention_bwd_static(const void* qkv, const unsigned char* keymask, const void* out, const void* dout,
+                            const float* lse, void* dqkv, int B, int L, int H, int head_dim, void* stream);
+
 /* bd_attention_fwd / bd_attention_bwd with dropout of the attention probabilities
  * (F.scaled_dot_product_attention(dropout_p), src/model/backbone.py:59-66): the softmax is
  * normalised over all visible keys, then each probability is dropped or scaled. `out` given to
