@@ -267,11 +267,27 @@ __global__ __launch_bounds__(64) void sample_step_kernel(bd_step_args p) {
       cmax = bd_wave_max(cmax);
       __syncthreads();
       int kk = needed < n_mask ? needed : n_mask;
-      // any masked slot whose softmax-over-positions weight is certainly non-zero?
+      // any masked slot whose softmax-over-positions weight is non-zero in fp32? The reference's softmax keeps
+      // denormals: the weight fl(fl(exp(x - max)) / Z) is positive down to about 104 - ln Z below the maximum
+      double zloc = 0.0;
+      for (int j = 0; j < CH; ++j) {
+        const int l = l0 + j;
+        if (l < L) zloc += exp((double)(s.col[l] - cmax));
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long zb = (unsigned long long)__double_as_longlong(zloc);
+        const unsigned int lo = __shfl_xor((unsigned int)zb, o, 64), hi = __shfl_xor((unsigned int)(zb >> 32), o, 64);
+        zloc += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+      }
       int anyv = 0;
       for (int j = 0; j < CH; ++j) {
         const int l = l0 + j;
-        if (l < L && (s.pf[l] & PF_MASK0) && s.col[l] >= cmax - 80.0f) anyv = 1;
+        if (l < L && (s.pf[l] & PF_MASK0)) {
+          const float delta = s.col[l] - cmax;
+          if (delta >= -87.0f) anyv = 1;
+          else if (delta >= -104.5f && rint(exp((double)delta) * 0x1p149) > 0.5 * zloc) anyv = 1;
+        }
       }
       anyv = bd_wave_sum_i(anyv);
       if (anyv > 0) {

@@ -53,6 +53,16 @@ CASES = {
                     scale=2.0, bias={_SF["[I+3]"]: 2.0}),
         "long70": dict(kind="sample", B=3, L=70, T=5, temperature=1.0, use_constraints=True, seed=205,
                        scale=2.0, bias={_SF["[I+3]"]: -2.0}),
+        # urgency boost when the masked slots' placeholder logits sit far below the column maximum: the reference
+        # boosts iff some masked slot's fp32 softmax-over-positions weight is non-zero (denormals included), which
+        # holds down to about 104 - ln Z below the maximum. "col_ramp" subtracts lo..hi from the placeholder column
+        # over the positions of the second half (the first half, unmasked early by "first_half_early", holds the maximum).
+        "urgency_85": dict(kind="sample", B=6, L=16, T=6, temperature=1.0, use_constraints=True, seed=209,
+                           scale=0.5, bias={_SF["[I+3]"]: -3.0}, col_ramp=(_SF["[I+3]"], 82.0, 86.0), first_half_early=True),
+        "urgency_95": dict(kind="sample", B=6, L=16, T=6, temperature=1.0, use_constraints=True, seed=210,
+                           scale=0.5, bias={_SF["[I+3]"]: -3.0}, col_ramp=(_SF["[I+3]"], 90.0, 108.0), first_half_early=True),
+        "urgency_110": dict(kind="sample", B=6, L=16, T=6, temperature=1.0, use_constraints=True, seed=211,
+                            scale=0.5, bias={_SF["[I+3]"]: -3.0}, col_ramp=(_SF["[I+3]"], 106.0, 115.0), first_half_early=True),
         # sample_conditional: prefix / suffix fixed, positions chosen among the non-fixed masks
         "conditional": dict(kind="conditional", B=6, L=18, T=7, temperature=1.0, use_constraints=True, seed=206,
                             scale=2.0, bias={_SF["[I+3]"]: 2.5}, prefix=[_SF["[C]"], _SF["[I+3]"]],
@@ -108,6 +118,10 @@ def step_logits(case, t, B, L, V):
     x = rs.standard_normal((B, L, V)) * case["scale"]
     for tok, bias in case.get("bias", {}).items():
         x[:, :, tok] += bias
+    if case.get("col_ramp"):
+        tok, lo, hi = case["col_ramp"]
+        half = L // 2
+        x[:, half:, tok] -= np.linspace(lo, hi, L - half)[None, :]
     x = x.astype(np.float32)
     if case.get("only"):
         keep = np.zeros(V, dtype=bool)
@@ -118,7 +132,11 @@ def step_logits(case, t, B, L, V):
 
 def step_u_sel(case, t, B, L):
     rs = np.random.RandomState(case["seed"] * 1000 + 500 + t)
-    return rs.random_sample((B, L)).astype(np.float32)
+    u = rs.random_sample((B, L)).astype(np.float32)
+    if case.get("first_half_early"):      # smaller keys in the first half: those positions are unmasked first
+        u[:, :L // 2] *= np.float32(0.25)
+        u[:, L // 2:] = np.float32(0.25) + u[:, L // 2:] * np.float32(0.75)
+    return u
 
 
 def step_u_tok(case, t, B, L, V):
