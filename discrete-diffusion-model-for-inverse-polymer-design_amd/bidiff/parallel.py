@@ -28,6 +28,70 @@ def allreduce_mean_(flat: torch.Tensor, world_size: int) -> torch.Tensor:
     return flat
 
 
+class GradientExchange:
+    """The training step's one exchange, cut into two buckets so that the first overlaps with the rest of the
+    backward pass (what DDP's bucketed all-reduce does in the reference, trainer_backbone.py:216-219).
+
+    The flat fp32 gradient buffer is laid out in parameter order, and backward produces gradients in reverse order:
+    the tail ``flat[split:]`` (upper layers, final norm, vocabulary head) is complete when the backward pass has
+    left layer ``split_layer``. ``tail_ready()`` is called at that point (by the backward pass, on the stream whose
+    work completes the tail) and starts an asynchronous all-reduce of the tail; ``finish()`` reduces the head,
+    waits for both and divides by the world size. If ``tail_ready`` was never called (accumulated gradients handed
+    to autograd, a backward pass without the hook) ``finish`` reduces the whole buffer in one call. Skipping both on
+    accumulation micro-steps is the reference's ``no_sync`` (:427-431)."""
+
+    def __init__(self, flat: torch.Tensor, split: int, world_size: int):
+        if not (0 <= split <= flat.numel()):
+            raise ValueError("GradientExchange: split outside the buffer")
+        self.flat, self.split, self.world = flat, int(split), int(world_size)
+        self._tail = None
+        self.armed = False
+
+    def _on(self):
+        return self.world > 1 and dist.is_available() and dist.is_initialized()
+
+    def arm(self):
+        """Before the backward pass of an optimizer step: the next ``tail_ready`` starts the tail's all-reduce."""
+        self.armed = True
+        self._tail = None
+
+    def tail_ready(self):
+        if not self.armed or self._tail is not None or not self._on() or self.split >= self.flat.numel() or self.split == 0:
+            return
+        self._tail = dist.all_reduce(self.flat[self.split:], op=dist.ReduceOp.SUM, async_op=True)
+
+    def finish(self):
+        self.armed = False
+        if not self._on():
+            return self.flat
+        if self._tail is None:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        else:
+            dist.all_reduce(self.flat[:self.split], op=dist.ReduceOp.SUM)
+            self._tail.wait()          # the current stream waits for the tail's collective
+            self._tail = None
+        self.flat.mul_(1.0 / self.world)
+        return self.flat
+
+
+def tail_split_offset(optimizer, backbone, split_layer: int):
+    """Offset in ``optimizer.flat_grad`` from which on the buffer holds exactly the parameters of
+    ``backbone.layers[split_layer:]``, the final norm and the vocabulary head; None if the optimizer's layout
+    does not end with that block (e.g. the Muon layout, which groups matrices by shape)."""
+    params, offsets = getattr(optimizer, "_params", None), getattr(optimizer, "_offsets", None)
+    if not params or not offsets or not (0 < split_layer < len(backbone.layers)):
+        return None
+    tail = [p for blk in list(backbone.layers)[split_layer:] for p in blk.parameters()]
+    tail += list(backbone.final_norm.parameters()) + list(backbone.output_proj.parameters())
+    tail = [p for p in tail if p.requires_grad]
+    if not tail or len(tail) >= len(params):
+        return None
+    got = params[len(params) - len(tail):]
+    if any(a is not b for a, b in zip(got, tail)):
+        return None
+    return int(offsets[len(params) - len(tail)])
+
+
 def sample_sharded(sampler, num_samples: int, seq_length: int, batch_size: int, rank: int, world_size: int,
                    lengths=None):
     """This rank's share of ``sample_batch(num_samples, ...)``; returns (ids list, strings, (start, stop))."""

@@ -42,6 +42,17 @@ def _side_stream(dev):
     return _SIDE[dev]
 
 
+# (callable, layer index): called once per backward pass, in direct-accumulation mode only, when every gradient of
+# the layers >= that index, the final norm and the vocabulary head has been enqueued - on the stream whose order
+# covers all of them (the weight-gradient stream when it is in use). The data-parallel trainer starts the
+# all-reduce of that part of the flat gradient buffer there (parallel.GradientExchange).
+_TAIL_HOOK = [None, -1]
+
+
+def set_tail_ready_hook(fn, layer_index: int = -1):
+    _TAIL_HOOK[0], _TAIL_HOOK[1] = fn, int(layer_index)
+
+
 def _ck(rc, what):
     if rc != 0:
         _lib.check(rc, what)
@@ -347,6 +358,9 @@ class _BackboneFn(torch.autograd.Function):
             done = torch.cuda.Event()
             done.record(side)
             handed[li] = done
+            if direct and _TAIL_HOOK[0] is not None and li == _TAIL_HOOK[1]:
+                with torch.cuda.stream(side):       # the side stream's order covers this layer's main-stream work too
+                    _TAIL_HOOK[0]()
 
         def wgrad_side(li, dY, X, dW, N, K, db):
             if side is None:
@@ -405,6 +419,8 @@ class _BackboneFn(torch.autograd.Function):
                     dx_bf16=dy_next if li > 0 else None, drop=drop, site=max(0, 4 * (li - 1) + 3))
             if side is not None:
                 hand_over(li)
+            elif direct and _TAIL_HOOK[0] is not None and li == _TAIL_HOOK[1]:
+                _TAIL_HOOK[0]()
         if drop is not None:
             _ck(lib.bd_dropout_f32(_lib.ptr(dx), _lib.ptr(dx), M, d, _dp(drop), 0, _s()), "bd_dropout_f32")
         _ck(lib.bd_embed_bwd(_lib.ptr(dx), _lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(gbuf(model.token_embedding.weight)),

@@ -22,7 +22,10 @@ from torch.optim.lr_scheduler import CosineAnnealingLR, LinearLR, SequentialLR
 
 from .optimizer import FlatAdamW  # noqa: F401
 from .optimizer_setup import build_step1_backbone_optimizer
-from ..parallel import allreduce_mean_
+import os
+
+from . import autograd as _autograd
+from ..parallel import GradientExchange, allreduce_mean_, tail_split_offset
 
 
 def _f(v, name):
@@ -82,6 +85,17 @@ class BackboneTrainer:
         cos = CosineAnnealingLR(self.optimizer, T_max=max(1, self.max_steps - self.warmup_steps), eta_min=1e-6)
         self.scheduler = SequentialLR(self.optimizer, schedulers=[warm, cos], milestones=[self.warmup_steps])
 
+        # data parallel: the gradient exchange in two buckets, the upper half of the network's gradients reduced
+        # while the lower half's backward still runs (BD_OVERLAP_ALLREDUCE=0: one blocking all-reduce per step)
+        self._exchange = None
+        if self.distributed and self.world_size > 1:
+            bb = getattr(self.model, "backbone", None)
+            split_layer = len(bb.layers) // 2 if bb is not None else 0
+            off = tail_split_offset(self.optimizer, bb, split_layer) if bb is not None else None
+            if off is None or os.environ.get("BD_OVERLAP_ALLREDUCE", "1") == "0":
+                off = self.optimizer.flat_grad.numel()           # nothing to start early
+            self._exchange = GradientExchange(self.optimizer.flat_grad, off, self.world_size)
+            _autograd.set_tail_ready_hook(self._exchange.tail_ready, split_layer)
         self.global_step = 0
         self.best_val_loss = float("inf")
         self.train_losses, self.val_losses, self.val_steps, self.learning_rates = [], [], [], []
@@ -108,9 +122,15 @@ class BackboneTrainer:
         without synchronising the host (reference _train_step, trainer_backbone.py:414-457)."""
         out = self.model(input_ids, attention_mask)
         loss = out["loss"] / self.grad_accum_steps
+        if should_step and self._exchange is not None:
+            self._exchange.arm()
         loss.backward()
         if should_step:
-            if self.distributed:
+            if self._exchange is not None:
+                if self._exchange._tail is None:
+                    self.optimizer.sync_grads()      # gradients autograd kept beside the flat buffer
+                self._exchange.finish()
+            elif self.distributed:
                 self.optimizer.sync_grads()
                 allreduce_mean_(self.optimizer.flat_grad, self.world_size)
             self.optimizer.step(max_norm=self.gradient_clip_norm)
