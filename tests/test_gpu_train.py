@@ -417,6 +417,47 @@ def test_optimizer_picks_up_gradients_unbound_by_model_zero_grad(gpu_device):
         opt.step()
 
 
+def test_tail_hook_fires_when_the_upper_layers_gradients_are_complete(gpu_device):
+    """The data-parallel exchange starts the all-reduce of flat_grad[split:] from a hook inside the backward pass:
+    what the hook sees there (a copy enqueued on the hook's stream) must already be the final gradients of the
+    layers >= split, the final norm and the vocabulary head, while the head of the buffer is still being written."""
+    from bidiff.parallel import tail_split_offset
+    dev = gpu_device
+    cfg = dict(RI.SMALL_CFG, vocab_size=39, num_layers=4, dropout=0.1)
+    torch.manual_seed(7)
+    bb = DiffusionBackbone(**cfg)
+    model = DiscreteMaskingDiffusion(bb, num_steps=cfg["num_diffusion_steps"], mask_token_id=1, pad_token_id=0,
+                                     bos_token_id=2, eos_token_id=3).to(dev).train()
+    ids, attn, t = (torch.from_numpy(x).to(dev) for x in RI.backbone_inputs(cfg, 33, B=64, L=128))
+    opt = FlatAdamW(model.parameters(), lr=1e-3)
+    off = tail_split_offset(opt, bb, 2)
+    assert off is not None and 0 < off < opt.flat_grad.numel()
+    first_tail = next(i for i, o in enumerate(opt._offsets) if o == off)
+    assert opt._params[first_tail] is bb.layers[2].norm1.weight
+    seen = []
+
+    def hook():
+        seen.append((opt.flat_grad[off:].clone(), opt.flat_grad[:off].clone()))
+
+    AG.set_tail_ready_hook(hook, 2)
+    try:
+        for _ in range(3):
+            opt.zero_grad()
+            seen.clear()
+            model(ids, attn)["loss"].backward()
+            torch.cuda.synchronize()
+            assert len(seen) == 1
+            assert torch.equal(seen[0][0], opt.flat_grad[off:]), "tail complete when the hook fires"
+            assert not torch.equal(seen[0][1], opt.flat_grad[:off]), "head still in progress"
+        # gradients not bound to the flat buffer: autograd accumulates after the backward pass, no early hook
+        model.zero_grad()
+        seen.clear()
+        model(ids, attn)["loss"].backward()
+        assert seen == []
+    finally:
+        AG.set_tail_ready_hook(None)
+
+
 def test_training_steps_follow_fp32_reference_trajectory(gpu_device):
     """Five optimizer steps (corruption, forward, backward, clip 1.0, AdamW) on the GPU next to the
     same five steps of the fp32 CPU restatement with torch.optim.AdamW: losses stay within bf16
