@@ -433,6 +433,10 @@ class DiffusionBackbone(nn.Module):
         """Hidden states [batch, seq_len, hidden] (reference backbone.py:259-299): ``layer_idx == -1``
         gives the final-norm output of the whole stack, ``layer_idx = i`` the residual stream after
         block i (no final norm)."""
+        if layer_idx == -1 and torch.is_grad_enabled() and any(p.requires_grad for p in self._params()):
+            # trainable backbone under autograd (a property head fine-tuning the last blocks): the training path
+            from ..training.autograd import backbone_forward_train
+            return backbone_forward_train(self, input_ids, timesteps, attention_mask, hidden_states=True)
         keymask = self._keymask_bytes(attention_mask, input_ids)
         if layer_idx != -1:
             if not 0 <= layer_idx < self.num_layers:
@@ -456,14 +460,23 @@ class DiffusionBackbone(nn.Module):
 
     def get_pooled_output(self, input_ids, timesteps, attention_mask=None, pooling: str = "mean"):
         """Masked mean / cls / max pooling of the final hidden states, [batch, hidden] fp32 (reference
-        backbone.py:301-335). One pooling kernel over the bf16 hidden rows the forward wrote; no
-        gradient flows through it (the backbone is a frozen feature extractor here)."""
+        backbone.py:301-335). Frozen backbone or no_grad: one pooling kernel over the bf16 hidden rows the
+        forward wrote. With trainable backbone parameters under autograd (PropertyPredictor with
+        finetune_last_layers > 0) the hidden states come from the training path and the pooling is
+        the reference's torch expression, so gradients reach the unfrozen blocks."""
         modes = {"mean": 0, "cls": 1, "max": 2}
         if pooling not in modes:
             raise ValueError(f"Unknown pooling method: {pooling}")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self._params()):
-            raise NotImplementedError("bidiff: get_pooled_output does not backpropagate into the backbone; freeze "
-                                      "it (requires_grad_(False)) or call under torch.no_grad()")
+            hs = self.get_hidden_states(input_ids, timesteps, attention_mask)
+            if pooling == "cls":
+                return hs[:, 0]
+            if attention_mask is None:
+                return hs.mean(dim=1) if pooling == "mean" else hs.max(dim=1)[0]
+            m = attention_mask.unsqueeze(-1).float()
+            if pooling == "mean":
+                return (hs * m).sum(dim=1) / m.sum(dim=1).clamp(min=1e-9)
+            return (hs * m + (1 - m) * (-1e9)).max(dim=1)[0]
         keymask = self._keymask_bytes(attention_mask, input_ids)
         hidden, _ = self.run_forward(input_ids, timesteps, keymask, want_hidden=True, want_logits=False)
         B, L = input_ids.shape

@@ -4,7 +4,8 @@ Drop-in for the reference's ``src/model/property_head.py``: ``PropertyHead`` (:8
 on the pooled hidden state, ``PropertyPredictor`` (:72-237) runs the backbone at a fixed timestep,
 pools and applies the head. The backbone forward and the pooling are HIP kernels
 (``DiffusionBackbone.get_pooled_output``); the head is a few hundred kFLOP per sequence and stays
-a torch module so that it trains with ordinary autograd on the frozen features.
+a torch module that trains with ordinary autograd, on frozen features or - ``finetune_last_layers`` -
+together with the last blocks, whose gradients the training-step backward kernels provide.
 """
 from typing import Dict, List, Optional
 
@@ -52,10 +53,14 @@ class PropertyPredictor(nn.Module):
             for p in self.backbone.parameters():
                 p.requires_grad = False
             if finetune_last_layers > 0:
-                # the reference unfreezes the last blocks and the final norm here
-                # (property_head.py:106-113); the HIP pooling path has no backward into the backbone
-                raise NotImplementedError("bidiff PropertyPredictor: finetune_last_layers > 0 is not built "
-                                          "(the pooled features do not backpropagate into the backbone)")
+                # the last blocks and the final norm train with the head (property_head.py:106-113): their
+                # gradients come from the training-step backward kernels, which stop below the lowest
+                # unfrozen block
+                for layer in self.backbone.layers[-finetune_last_layers:]:
+                    for p in layer.parameters():
+                        p.requires_grad = True
+                for p in self.backbone.final_norm.parameters():
+                    p.requires_grad = True
 
     def forward(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                 timesteps: Optional[torch.Tensor] = None) -> torch.Tensor:

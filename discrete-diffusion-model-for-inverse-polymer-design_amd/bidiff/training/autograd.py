@@ -225,7 +225,10 @@ def _train_weights(model):
 
 class _BackboneFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, ids, timesteps, keymask, *params):
+    def forward(ctx, model, ids, timesteps, keymask, mode, *params):
+        """mode 0: logits [B, L, V] (the diffusion training step); mode 1: the final-norm hidden states
+        [B, L, d] in fp32 (what get_hidden_states / get_pooled_output return to a property head that
+        fine-tunes the last blocks, reference property_head.py:102-112)."""
         _enter()
         lib = _lib.lib()
         B, L = ids.shape
@@ -270,13 +273,19 @@ class _BackboneFn(torch.autograd.Function):
             saved.append(s)
             x = x_out
         stf = torch.empty(M, 2, device=dev)
+        ctx.model, ctx.saved, ctx.tw, ctx.drop, ctx.mode = model, saved, tw, drop, int(mode)
+        ctx.ids, ctx.timesteps, ctx.keymask = ids, timesteps, keymask
+        if mode == 1:
+            hid = torch.empty(B, L, d, device=dev)
+            _ck(lib.bd_layernorm(_lib.ptr(x), _lib.ptr(model.final_norm.weight), _lib.ptr(model.final_norm.bias), None,
+                                 _lib.ptr(hid), _lib.ptr(stf), M, d, eps, _s()), "bd_layernorm")
+            ctx.x_last, ctx.stf, ctx.hf = x, stf, None
+            return hid
         hf = torch.empty(M, d, dtype=bf, device=dev)
         _ln(x, model.final_norm.weight, model.final_norm.bias, hf, stf, M, d, eps)
         logits = torch.empty(B, L, V, device=dev)
         _gemm(hf, tw.wout, None, logits, M, tw.vpad, V, d, V, 3)
-        ctx.model, ctx.saved, ctx.tw, ctx.drop = model, saved, tw, drop
         ctx.x_last, ctx.stf, ctx.hf = x, stf, hf
-        ctx.ids, ctx.timesteps, ctx.keymask = ids, timesteps, keymask
         return logits
 
     @staticmethod
@@ -309,19 +318,29 @@ class _BackboneFn(torch.autograd.Function):
         def zeros(*shape):
             return torch.zeros(*shape, device=dev)
 
-        # vocabulary head (rows padded to a multiple of 128: own buffer, then one add / slice)
-        dl = torch.zeros(M, tw.vpad, dtype=bf, device=dev)
-        dl[:, :V] = dlogits.reshape(M, V)
-        dwout = zeros(tw.vpad, d)
-        _wgrad(dl, ctx.hf, dwout, M, tw.vpad, d)
-        if direct and model.output_proj.weight.requires_grad:
-            model.output_proj.weight.grad.add_(dwout[:V])
-        else:
-            grads[model.output_proj.weight] = dwout[:V]
         dh_buf = torch.empty(M, d, dtype=bf, device=dev)
-        _gemm(dl, tw.woutT, None, dh_buf, M, d, d, tw.vpad, d, 0)
+        if ctx.mode == 1:
+            # the incoming gradient is that of the final-norm output itself
+            _to_bf16(dlogits.reshape(M, d).float().contiguous(), dh_buf)
+        else:
+            # vocabulary head (rows padded to a multiple of 128: own buffer, then one add / slice)
+            dl = torch.zeros(M, tw.vpad, dtype=bf, device=dev)
+            dl[:, :V] = dlogits.reshape(M, V)
+            dwout = zeros(tw.vpad, d)
+            _wgrad(dl, ctx.hf, dwout, M, tw.vpad, d)
+            if direct and model.output_proj.weight.requires_grad:
+                model.output_proj.weight.grad.add_(dwout[:V])
+            else:
+                grads[model.output_proj.weight] = dwout[:V]
+            _gemm(dl, tw.woutT, None, dh_buf, M, d, d, tw.vpad, d, 0)
         dx = torch.empty(M, d, device=dev)
         n_layers = len(model.layers)
+        # the chain stops below the lowest block with a trainable parameter (a property head fine-tuning the last
+        # blocks leaves the rest frozen); the embeddings need it all the way down
+        need_embed = any(p.requires_grad for e in (model.token_embedding, model.position_embedding,
+                                                   model.timestep_embedding) for p in e.parameters())
+        stop_layer = 0 if need_embed else next(
+            (i for i, blk in enumerate(model.layers) if any(p.requires_grad for p in blk.parameters())), n_layers)
         aw, dh, dhp, padded = tw.aw, tw.dh, tw.dhp, tw.dhp != tw.dh
 
         # The weight-gradient GEMMs feed nothing further down the chain, so they run on a second stream beside
@@ -366,7 +385,7 @@ class _BackboneFn(torch.autograd.Function):
             if side is None:
                 return _wgrad(dY, X, dW, M, N, K, db=db)
             pending.append((dY, X, dW, M, N, K, db))
-            if li == 0:
+            if li == stop_layer:
                 hand_over(li)
 
         # every LayerNorm backward also emits the bf16 gradient the next branch reads (with the fc2-output
@@ -380,6 +399,8 @@ class _BackboneFn(torch.autograd.Function):
         delta = torch.empty(B, H, L, device=dev)
         for li, blk, w, s in zip(reversed(range(len(model.layers))), reversed(model.layers), reversed(tw.layers),
                                  reversed(ctx.saved)):
+            if li < stop_layer:
+                break
             a = blk.attn
             ev = handed.pop(li + 2, None)
             if ev is not None:
@@ -416,21 +437,22 @@ class _BackboneFn(torch.autograd.Function):
                     gbuf(proj.bias).view(H, dh).add_(tb_[i].view(H, dhp)[:, :dh], alpha=f)
             _gemm(dqkv, w["wqkvT"], None, dh_buf, M, d, d, 3 * aw, d, 0)
             _ln_bwd(dh_buf, s["x_in"], s["st1"], blk.norm1.weight, dx, dx, gbuf(blk.norm1.weight), gbuf(blk.norm1.bias), M, d,
-                    dx_bf16=dy_next if li > 0 else None, drop=drop, site=max(0, 4 * (li - 1) + 3))
+                    dx_bf16=dy_next if li > stop_layer else None, drop=drop, site=max(0, 4 * (li - 1) + 3))
             if side is not None:
                 hand_over(li)
             elif direct and _TAIL_HOOK[0] is not None and li == _TAIL_HOOK[1]:
                 _TAIL_HOOK[0]()
-        if drop is not None:
+        if need_embed and drop is not None:
             _ck(lib.bd_dropout_f32(_lib.ptr(dx), _lib.ptr(dx), M, d, _dp(drop), 0, _s()), "bd_dropout_f32")
-        _ck(lib.bd_embed_bwd(_lib.ptr(dx), _lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(gbuf(model.token_embedding.weight)),
-                             _lib.ptr(gbuf(model.position_embedding.weight)),
-                             _lib.ptr(gbuf(model.timestep_embedding.weight)), B, L, d, int(model.pad_token_id), V,
-                             model.max_position_embeddings, model.num_diffusion_steps + 1, _s()),
-            "bd_embed_bwd")
+        if need_embed:
+            _ck(lib.bd_embed_bwd(_lib.ptr(dx), _lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(gbuf(model.token_embedding.weight)),
+                                 _lib.ptr(gbuf(model.position_embedding.weight)),
+                                 _lib.ptr(gbuf(model.timestep_embedding.weight)), B, L, d, int(model.pad_token_id), V,
+                                 model.max_position_embeddings, model.num_diffusion_steps + 1, _s()),
+                "bd_embed_bwd")
         if side is not None:
             main.wait_stream(side)       # every gradient is complete before autograd / the optimizer go on
-        out = [None, None, None, None]
+        out = [None, None, None, None, None]
         for p in params:
             g = grads.get(p)
             out.append(g if (g is not None and p.requires_grad) else None)
@@ -438,7 +460,8 @@ class _BackboneFn(torch.autograd.Function):
         return tuple(out)
 
 
-def backbone_forward_train(model, input_ids, timesteps, attention_mask):
+def backbone_forward_train(model, input_ids, timesteps, attention_mask, hidden_states=False):
+    """Training forward: logits, or (``hidden_states=True``) the fp32 final-norm hidden states."""
     _lib.require_device(input_ids, "DiffusionBackbone.forward")
     if model.hidden_size % 128 or model.ffn_hidden_size % 128:
         raise ValueError("bidiff training path needs hidden and ffn sizes that are multiples of 128")
@@ -448,7 +471,7 @@ def backbone_forward_train(model, input_ids, timesteps, attention_mask):
     for p in model._params():
         if p.dtype != torch.float32 or not p.is_contiguous():
             raise RuntimeError("bidiff training path expects contiguous fp32 parameters")
-    return _BackboneFn.apply(model, ids, timesteps, keymask, *model._params())
+    return _BackboneFn.apply(model, ids, timesteps, keymask, 1 if hidden_states else 0, *model._params())
 
 
 class _MaskedCE(torch.autograd.Function):

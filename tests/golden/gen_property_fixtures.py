@@ -60,6 +60,22 @@ def main():
         for k, p in head.named_parameters():
             blob[f"{name}/grad/{k}"] = p.grad.numpy().copy()
         blob[f"{name}/labels"] = labels.numpy()
+        # fine-tuning the last N blocks + final norm with the head (property_head.py:102-112): gradients of every
+        # parameter the reference unfreezes, and the list of those parameters (eval mode: dropout off)
+        for n_ft in (1, 2):
+            if n_ft > cfg["num_layers"]:
+                continue
+            for pooling in ("mean", "max"):
+                pp = PropertyPredictor(bb, head, freeze_backbone=True, finetune_last_layers=n_ft, pooling=pooling,
+                                       default_timestep=1).eval()
+                pp.zero_grad()
+                pp.compute_loss(ti, labels, ta)["loss"].backward()
+                names = []
+                for k, p in pp.named_parameters():
+                    if p.requires_grad:
+                        names.append(k)
+                        blob[f"{name}/ft{n_ft}/{pooling}/{k}"] = p.grad.numpy().copy()
+                meta[f"{name}_ft{n_ft}_trainable"] = names
     np.savez_compressed(os.path.join(HERE, "property.npz"), **blob)
     json.dump(meta, open(os.path.join(HERE, "property_meta.json"), "w"), indent=1, sort_keys=True)
     print("wrote", len(blob), "arrays")

@@ -84,7 +84,7 @@ def test_property_predictor_matches_reference_golden(gpu_device, name):
 
 def test_pooled_output_at_bench_shape_matches_oracle_and_guards(gpu_device):
     """d = 384 small backbone through the single-launch forward + pooling kernel vs the fp32 oracle;
-    an unfrozen backbone under autograd is refused (no backward through the pooled features)."""
+    an unfrozen backbone under autograd takes the training path."""
     dev = gpu_device
     from bidiff.model.backbone import DiffusionBackbone
     cfg = dict(RI.SMALL_CFG, num_layers=2, dropout=0.0)
@@ -100,8 +100,66 @@ def test_pooled_output_at_bench_shape_matches_oracle_and_guards(gpu_device):
             got = bb.get_pooled_output(ids.to(dev), t.to(dev), attn.to(dev), pooling).cpu()
             want = BR.pooled_output(sd, cfg, ids, t, attn, pooling)
         assert rel(got.numpy(), want.numpy()) < BF16_TOL, pooling
-    with pytest.raises(NotImplementedError):
-        bb.get_pooled_output(ids.to(dev), t.to(dev), attn.to(dev), "mean")
+    # an unfrozen backbone under autograd: the training path, pooled by the reference's torch expression
+    bb.train()
+    got = bb.get_pooled_output(ids.to(dev), t.to(dev), attn.to(dev), "mean")
+    assert got.requires_grad and rel(got.detach().cpu().numpy(), BR.pooled_output(sd, cfg, ids, t, attn, "mean").numpy()) < BF16_TOL
     with pytest.raises(ValueError):
         with torch.no_grad():
             bb.get_pooled_output(ids.to(dev), t.to(dev), attn.to(dev), "median")
+
+
+@pytest.mark.parametrize("name,n_ft", [("tiny_h2", 1), ("tiny_h2", 2), ("tiny_h4", 1)])
+def test_finetune_last_layers_gradients_match_reference(gpu_device, name, n_ft):
+    """PropertyPredictor(freeze_backbone=True, finetune_last_layers=N): the reference unfreezes the last N blocks
+    and the final norm (property_head.py:102-112). Same set of trainable parameters, and the gradients of the MSE
+    loss for all of them (backbone blocks through the training-step backward kernels, which stop below the lowest
+    unfrozen block) against the vectors the reference's autograd produced."""
+    import json
+    dev = gpu_device
+    meta = json.load(open(os.path.join(H.GOLDEN, "property_meta.json")))
+    cfg, bb, head, ids, attn, t = setup(name)
+    bb, head = bb.to(dev), head.to(dev)
+    ti, ta = ids.to(dev), attn.to(dev)
+    labels = torch.from_numpy(BLOB[f"{name}/labels"]).to(dev)
+    sd_cpu = {"backbone." + k: v.detach().cpu().clone() for k, v in bb.state_dict().items()}
+    hsd_cpu = {k: v.detach().cpu().clone() for k, v in head.state_dict().items()}
+    t1 = torch.full((ids.shape[0],), 1, dtype=torch.long)
+    for pooling in ("mean", "max"):
+        # yardstick: how far the CPU restatement under bf16 autocast (the reference's training precision) lands from
+        # the reference's fp32 gradients on these five short sequences
+        ac = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd_cpu.items()}
+        ach = {k: v.clone().requires_grad_(True) for k, v in hsd_cpu.items()}
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            pred = BR.property_head(ach, BR.pooled_output(ac, cfg, ids, t1, attn, pooling, prefix="backbone."))
+        torch.nn.functional.mse_loss(pred.float(), torch.from_numpy(BLOB[f"{name}/labels"]).unsqueeze(-1)).backward()
+        pp = PropertyPredictor(bb, head, freeze_backbone=True, finetune_last_layers=n_ft, pooling=pooling,
+                               default_timestep=1).eval()
+        names = [k for k, p in pp.named_parameters() if p.requires_grad]
+        assert names == meta[f"{name}_ft{n_ft}_trainable"]
+        pp.zero_grad()
+        out = pp.compute_loss(ti, labels, ta)
+        out["loss"].backward()
+        for k, p in pp.named_parameters():
+            if not p.requires_grad:
+                assert p.grad is None, k
+                continue
+            want = BLOB[f"{name}/ft{n_ft}/{pooling}/{k}"]
+            if k.endswith("k_proj.bias"):      # true gradient is zero (softmax shift invariance)
+                assert np.linalg.norm(p.grad.cpu().numpy()) < 0.1 * np.linalg.norm(BLOB[f"{name}/ft{n_ft}/{pooling}/{k.replace('k_proj', 'q_proj')}"]) + 1e-9
+                continue
+            e = rel(p.grad.cpu().numpy(), want)
+            g_ac = (ac[k] if k.startswith("backbone.") else ach[k[len("property_head."):]]).grad
+            e_ac = rel(g_ac.float().numpy(), want)
+            # the tiny-shape bar of the training-step tests (1e-1: five short sequences, and max pooling routes one
+            # row per feature, so little averages out; the full-size training-step test holds 2e-2), or 1.5 x what
+            # bf16 autocast itself loses on the tensor
+            assert e < max(1e-1, 1.5 * e_ac), (k, pooling, e, e_ac)
+    # one optimizer step moves the unfrozen blocks and the head, nothing else
+    before = {k: p.detach().clone() for k, p in pp.named_parameters()}
+    opt = torch.optim.AdamW([p for p in pp.parameters() if p.requires_grad], lr=1e-3)
+    opt.zero_grad()
+    pp.compute_loss(ti, labels, ta)["loss"].backward()
+    opt.step()
+    for k, p in pp.named_parameters():
+        assert torch.equal(before[k], p.detach()) != p.requires_grad or k.endswith("k_proj.bias"), k

@@ -93,8 +93,11 @@ def test_predictor_checkpoint_layout_and_guards(tmp_path):
     torch.save({"something": 1}, path)
     with pytest.raises(KeyError):
         pp2.load_property_head(path)
-    with pytest.raises(NotImplementedError):
-        PropertyPredictor(bb, head, freeze_backbone=True, finetune_last_layers=1)
+    # finetune_last_layers unfreezes exactly what the reference does (property_head.py:106-113)
+    ft = PropertyPredictor(bb, head, freeze_backbone=True, finetune_last_layers=1)
+    assert [k for k, p_ in ft.named_parameters() if p_.requires_grad] == META["tiny_h2_ft1_trainable"]
+    PropertyPredictor(bb, head, freeze_backbone=True)
+    assert not any(p_.requires_grad for p_ in bb.parameters())
     # no CPU execution path: the product refuses host tensors instead of falling back
     with pytest.raises(RuntimeError):
         pp.predict(ids, attn)
