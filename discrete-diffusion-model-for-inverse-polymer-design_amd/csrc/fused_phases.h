@@ -14,7 +14,9 @@ typedef __attribute__((address_space(3))) bf16x8* lds_frag_w;
 typedef const __attribute__((address_space(3))) f32x4* lds_f4;
 typedef const __attribute__((address_space(3))) float* lds_f1;
 
-struct Gelu4 { float x[4], s[4], p[4]; };
+// four values of the GELU in flight, as two packed f16 pairs: input, its square, the polynomial
+struct Gelu4 { unsigned x[2], s[2], p[2]; };
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // bytes of LDS the phases need
 __host__ __device__ constexpr size_t ffn_phase_lds(int NT, int F) { return 6 * (size_t)NT * 1024 + ((size_t)F + 64) * 4; }
@@ -142,45 +144,52 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
   const unsigned ldsb = (unsigned)(size_t)(lds_void*)sb1 + 16 * h;
 
   f32x16 hn_cur, hn_next;      // GEMM1 results of chunk j and j + 1 (rows = hidden units of the chunk)
-  bf16x8 hb[2], hb0_next;      // GELU(hn_cur) as the two B operands of GEMM2; first half of the next
+  u32x4 hb[2], hb0_next;       // GELU(hn_cur) as the two B operands (8 f16 each) of GEMM2; first half of the next
   Gelu4 gs = {};
 
-  // GELU part g (0..47) of a 16-value tile: quad g / 12 = registers 4 quad .. 4 quad + 3 of the source tile, in twelve
-  // parts of ONE operation on each of the four values. Four independent chains: a vector operation that needs the
-  // result of the one issued two slots earlier waits for it (two interleaved chains cost 8 cycles per dependent
-  // operation beside MFMAs, four chains cost the 4 cycles of their issue).
-  auto gelu_part = [&](int g, const f32x16& src, bf16x8& dst) {
-    const int quad = g / 12, part = g % 12;
-    constexpr float C[8] = {-1.903182666e-09f, 1.410586241e-07f, -4.565313249e-06f, 8.634553992e-05f,
-                            -1.085383136e-03f, 9.789848745e-03f, -6.636063135e-02f, 3.989269649e-01f};
-    if (part == 0) {
+  // GELU in packed f16, two values per instruction: x = cvt_pkrtz(fp32 pair), s = min(x^2, 2.9^2),
+  // GELU(x) = x * clamp(0.5 + x P(s), 0, 1) with P a cubic minimax fit of (Phi(x) - 0.5) / x on |x| <= 2.9 (past
+  // that the product overshoots +-0.5 and the clamp saturates it); the result pair IS a dword of the f16 B operand
+  // of the second GEMM, whose weight fragments are stored as f16 (bd_ffn_pack_weights; bf16 values are exact in
+  // f16). |error| < 6.4e-3 absolute, rms 1.7e-3, against 1.6e-2 / 4.8e-3 for rounding the exact GELU to bf16 (what
+  // the unfused path does). 8 packed operations per pair = 4 per value (the fp32 form took 12): the vector work of
+  // a feed-forward step drops from 16 to 5 cycles beside its MFMA.
+  // GELU part g (0..31) of a 16-value tile: quad g / 8 = registers 4 quad .. 4 quad + 3 of the source tile, in
+  // eight parts of ONE packed operation on each of its two pairs.
+  constexpr unsigned GC0 = 0x8c018c01u, GC1 = 0x1e081e08u, GC2 = 0xab87ab87u, GC3 = 0x36513651u;   // cubic, high to low
+  constexpr unsigned GX2 = 0x48344834u, GHALF = 0x38003800u;                                        // 2.9^2, 0.5
+  unsigned gc0v = GC0;
+  asm volatile("" : "+v"(gc0v));
+  auto gelu_part = [&](int g, const f32x16& src, u32x4& dst) {
+    const int quad = g / 8, part = g % 8;
 #pragma unroll
-      for (int v = 0; v < 4; ++v) { gs.x[v] = src[4 * quad + v]; gs.s[v] = gs.x[v] * gs.x[v]; }
-    } else if (part == 1) {
-#pragma unroll
-      for (int v = 0; v < 4; ++v) asm("v_min_f32 %0, 0x41800000, %1" : "=v"(gs.s[v]) : "v"(gs.s[v]));   // min(s, 16); fminf() adds a canonicalising max here
-    } else if (part == 2) {
-#pragma unroll
-      for (int v = 0; v < 4; ++v) gs.p[v] = gs.s[v] * C[0] + C[1];
-    } else if (part <= 8) {
-#pragma unroll
-      for (int v = 0; v < 4; ++v) gs.p[v] = gs.p[v] * gs.s[v] + C[part - 1];
-    } else if (part == 9) {
-#pragma unroll
-      for (int v = 0; v < 4; ++v) gs.p[v] = __builtin_amdgcn_fmed3f(gs.x[v] * gs.p[v] + 0.5f, 0.0f, 1.0f);
-    } else if (part == 10) {
-#pragma unroll
-      for (int v = 0; v < 4; ++v) gs.p[v] = gs.x[v] * gs.p[v];
-    } else {
-      // registers 4 quad + v of a 32x32 tile are rows 8 quad + 4 h + v: operand elements 4 (quad % 2) + v of k-block quad / 2
-      const int j0 = 4 * (quad & 1);
-#pragma unroll
-      for (int v = 0; v < 4; ++v) dst[j0 + v] = (__bf16)gs.p[v];
-      asm volatile("" : "+v"(dst));
+    for (int pr = 0; pr < 2; ++pr) {
+      if (part == 0) {
+        asm("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(gs.x[pr]) : "v"(src[4 * quad + 2 * pr]), "v"(src[4 * quad + 2 * pr + 1]));
+      } else if (part == 1) {
+        asm("v_pk_mul_f16 %0, %1, %1" : "=v"(gs.s[pr]) : "v"(gs.x[pr]));
+      } else if (part == 2) {
+        asm("v_pk_min_f16 %0, %1, %2" : "=v"(gs.s[pr]) : "v"(gs.s[pr]), "s"(GX2));
+      } else if (part == 3) {
+        asm("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(gs.p[pr]) : "v"(gc0v), "v"(gs.s[pr]), "s"(GC1));
+      } else if (part == 4) {
+        asm("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(gs.p[pr]) : "v"(gs.p[pr]), "v"(gs.s[pr]), "s"(GC2));
+      } else if (part == 5) {
+        asm("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(gs.p[pr]) : "v"(gs.p[pr]), "v"(gs.s[pr]), "s"(GC3));
+      } else if (part == 6) {
+        asm("v_pk_fma_f16 %0, %1, %2, %3 clamp" : "=v"(gs.p[pr]) : "v"(gs.x[pr]), "v"(gs.p[pr]), "s"(GHALF));
+      } else {
+        // registers 4 quad + v of a 32x32 tile are rows 8 quad + 4 h + v: operand elements 4 (quad % 2) + v of
+        // k-block quad / 2, i.e. dword 2 (quad % 2) + pr of that operand
+        unsigned r;
+        asm("v_pk_mul_f16 %0, %1, %2" : "=v"(r) : "v"(gs.x[pr]), "v"(gs.p[pr]));
+        dst[2 * (quad & 1) + pr] = r;
+      }
     }
-#pragma unroll
-    for (int v = 0; v < 4; ++v) asm volatile("" : "+v"(gs.s[v]), "+v"(gs.p[v]));
+    if (part == 7) asm volatile("" : "+v"(dst));
+    asm volatile("" : "+v"(gs.x[0]), "+v"(gs.x[1]), "+v"(gs.s[0]), "+v"(gs.s[1]), "+v"(gs.p[0]), "+v"(gs.p[1]));
   };
+  constexpr int GH = 16;       // GELU parts per half tile (two quads)
 
   // units 0, 1, 2 landed (3 and 4 may still be in flight), bias table written
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_UNIT) : "memory");
@@ -197,10 +206,10 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
 #pragma unroll
     for (int i = 0; i < NT; ++i) hn_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(lds_frag)(size_t)(lds0 + i * 1024), xln[i], hn_next, 0, 0, 0);
 #pragma unroll
-    for (int g = 0; g < 24; ++g) gelu_part(g, hn_next, hb0_next);
+    for (int g = 0; g < GH; ++g) gelu_part(g, hn_next, hb0_next);
     hn_cur = hn_next;
     hb[0] = hb0_next;
-    hb[1] = xln[0];                  // defined value; overwritten before its first real use
+    hb[1] = hb0_next;                // defined value; overwritten before its first real use
     // every wave is done with unit 0: unit 6 takes its slot (the loop issues odd units from 5, even units from 8)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -311,18 +320,19 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
       if (i < NT) {
         // second half of GELU(hn_cur) -> hb[1], beside GEMM1
 #pragma unroll
-        for (int g = 24 + i * 24 / NT; g < 24 + (i + 1) * 24 / NT; ++g) gelu_part(g, hn_cur, hb[1]);
+        for (int g = GH + i * GH / NT; g < GH + (i + 1) * GH / NT; ++g) gelu_part(g, hn_cur, hb[1]);
       } else {
         // first half of GELU(hn_next) -> hb0_next, beside GEMM2
 #pragma unroll
-        for (int g = (i - NT) * 24 / NT; g < (i - NT + 1) * 24 / NT; ++g) gelu_part(g, hn_next, hb0_next);
+        for (int g = (i - NT) * GH / NT; g < (i - NT + 1) * GH / NT; ++g) gelu_part(g, hn_next, hb0_next);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (i < NT) {
         hn_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xln[i], hn_next, 0, 0, 0);
       } else {
         const int T = (i - NT) >> 1, kk = (i - NT) & 1;
-        acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], hb[kk], acc[T], 0, 0, 0);
+        acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[i]), __builtin_bit_cast(f16x8, hb[kk]),
+                                                        acc[T], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);     // nothing moves between fragment steps
     }

@@ -92,6 +92,8 @@ int bd_gemm_panel(const void* A, const void* W, const float* bias, void* out, co
  *     out = x + W2 * GELU(W1' * normalise(x) + b1') + b2        (x, out: fp32 [M, d]; may alias)
  * normalise = LayerNorm without affine; the caller folds gamma into W1 (W1' = W1 * gamma) and beta
  * into b1 (b1' = b1 + W1 * beta). The [M, F] hidden activations are never written to memory.
+ * The GELU runs in packed f16 and feeds the second product on the f16 matrix instruction (W2 is stored as f16 in
+ * the stream; every bf16 weight of normal f16 magnitude converts exactly).
  * wpack is the weight stream made by bd_ffn_pack_weights from W1' (bf16 [F, d]) and W2 (bf16 [d, F]);
  * it holds bd_ffn_pack_bytes(d, F) bytes. Supported: d in {128, 256, 384}, F % 32 == 0, F <= 4096.
  * Replaces TransformerBlock.forward's  x + ffn(ln2(x))  (src/model/backbone.py:128, FeedForward :85-96). */
