@@ -153,6 +153,7 @@ def train_bench(dev, rank, world, steps, warmup, cpu_steps, threads, batch=256, 
     ids, attn = bpe_batch(batch, L, V, 1 + rank)
     ids_d, attn_d = torch.from_numpy(ids).to(dev), torch.from_numpy(attn).to(dev)
     tokens = int(attn.sum())
+    lens = attn.sum(1).tolist()       # host-side lengths, as a data loader knows them: no device round trip
 
     # the exchange in two buckets: the upper three layers' gradients (plus final norm and vocabulary head) are
     # all-reduced while the lower three layers' backward runs (BD_OVERLAP_ALLREDUCE=0: one blocking all-reduce)
@@ -165,7 +166,7 @@ def train_bench(dev, rank, world, steps, warmup, cpu_steps, threads, batch=256, 
         AG.set_tail_ready_hook(exchange.tail_ready, 3)
 
     def step():
-        out = model(ids_d, attn_d)
+        out = model(ids_d, attn_d, lengths=lens)
         if exchange is not None:
             exchange.arm()
         out["loss"].backward()
@@ -211,17 +212,39 @@ def train_bench(dev, rank, world, steps, warmup, cpu_steps, threads, batch=256, 
         step()
     torch.cuda.synchronize()
     table = prof_table(lib, 1e3 * (time.perf_counter() - t0))
-    flops_step = 3.0 * fwd_flops_per_token(384, 6, 1536, L, V) * batch * L       # forward + 2x backward, padded rows included
+    # the same step with every padded row computed (skip_padded_rows off), for comparison
+    model.skip_padded_rows = False
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_all = max(3, steps // 4)
+    for _ in range(n_all):
+        step()
+    torch.cuda.synchronize()
+    ms_all_rows = 1e3 * (time.perf_counter() - t0) / n_all
+    model.skip_padded_rows = True
+    # flops of the rows that are computed: projections, feed-forward and head per packed row (rounded up to 128
+    # rows), attention per sequence over its own length; forward + 2x backward
+    rows = (tokens + 127) // 128 * 128
+    per_row = 2 * 6 * (4 * 384 * 384 + 2 * 384 * 1536) + 2 * 384 * V
+    flops_step = 3.0 * (per_row * rows + 4 * 6 * 384 * float(sum(n * n for n in lens)))
+    flops_all_rows = 3.0 * fwd_flops_per_token(384, 6, 1536, L, V) * batch * L
     tfl = flops_step / (ms_step * 1e-3) / 1e12
     res = {"metric": "train non-pad tokens/sec (Bi_Diffusion_SMILES_BPE training step)",
            "value": float(tok.item()) * steps / el, "unit": "non-pad tokens/s",
-           "padded_tokens_per_s": world * batch * L * steps / el, "ms_per_step": ms_step,
+           "ms_per_step": ms_step, "rows_computed_per_step": rows, "rows_padded_layout": batch * L,
+           "all_rows_variant": {"ms_per_step": ms_all_rows, "value": tokens / (ms_all_rows * 1e-3),
+                                "tflops": flops_all_rows / (ms_all_rows * 1e-3) / 1e12,
+                                "note": "skip_padded_rows = False: all B*L rows computed, as the reference does"},
            "steps": steps, "warmup": warmup, "final_loss": final_loss, "dtype": "bf16",
            "config": {"workload": f"SMILES_BPE small backbone (V=803, T=50), per-GPU batch {batch}, L={L} padded, "
-                                  f"{tokens} non-pad tokens per rank-batch, dropout 0.1 at all four sites (in-kernel Philox), AdamW + clip 1.0",
+                                  f"{tokens} non-pad tokens per rank-batch, dropout 0.1 at all four sites (in-kernel Philox), AdamW + clip 1.0; "
+                                  f"rows behind each sequence's last token are left out of the kernels (no loss, no gradient, "
+                                  f"no influence on other rows; same loss and gradients)",
                       "parallelism": f"dp{world}, flat gradient buffer all-reduced per step in two buckets, the first "
                                      f"overlapped with the lower layers' backward"},
-           # whole step against the MFMA roofline: 3 x forward flops of every padded token / step time
+           # whole step against the MFMA roofline: 3 x forward flops of the computed rows / step time
            "roofline": {"bound": "mfma", "kernel": "whole training step (forward + backward + clip + AdamW)",
                         "achieved": tfl, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / MFMA_BF16_PEAK_TFLOPS,
                         "flops_per_step": flops_step, "traffic": None,

@@ -135,6 +135,12 @@ SIGNATURES = {
     "bd_attention_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "bd_attention_bwd_static_capacity": (C.c_longlong, []),
     "bd_attention_bwd_static": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
+    "bd_build_rowmap": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP]),
+    "bd_embed_rows": (C.c_int, [VP, VP, VP, VP, VP, VP, VP] + [C.c_int] * 6 + [VP, C.c_uint, VP]),
+    "bd_attention_fwd_varlen": (C.c_int, [VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, C.c_uint, VP]),
+    "bd_attention_bwd_varlen": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP,
+                                          C.c_uint, VP]),
+    "bd_embed_bwd_varlen": (C.c_int, [VP, VP, VP, VP, VP, VP, VP] + [C.c_int] * 7 + [VP]),
     "bd_embed_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP] + [C.c_int] * 7 + [VP]),
     "bd_sumsq_f32": (C.c_int, [VP, C.c_longlong, VP, VP]),
     "bd_adamw_step": (C.c_int, [VP, VP, VP, VP, C.c_longlong] + [C.c_float] * 7 + [VP, C.c_float, VP]),

@@ -47,7 +47,8 @@ class DeviceBatchLoader:
                                          self.store.pad_token_id, _lib.ptr(ids), _lib.ptr(mask), _lib.ptr(self._err),
                                          _lib.stream_handle())
         _lib.check(rc, "bd_collate_batch")
-        return {"input_ids": ids, "attention_mask": mask}
+        # "lengths" (host integers) lets the training step lay out its packed rows without a device round trip
+        return {"input_ids": ids, "attention_mask": mask, "lengths": np.minimum(self.store.lengths[idx], L)}
 
     def _upload_indices(self, idx, B):
         if len(self._ring) < self.ring_slots:

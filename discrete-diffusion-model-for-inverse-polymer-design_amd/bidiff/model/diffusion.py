@@ -40,6 +40,9 @@ class DiscreteMaskingDiffusion(nn.Module):
         # "torch": uniforms from torch.rand (follows torch.manual_seed like the reference);
         # "philox": in-kernel counter-based stream seeded from torch's generator per call.
         self.corruption_rng = "torch"
+        # training forward: leave out the rows behind each sequence's last attended position (no loss, no gradient
+        # and no influence on other rows comes from them; the returned logits are zero there). False = every row.
+        self.skip_padded_rows = True
         self.register_buffer("mask_schedule", self._compute_mask_schedule())
 
     def _compute_mask_schedule(self) -> torch.Tensor:
@@ -91,14 +94,25 @@ class DiscreteMaskingDiffusion(nn.Module):
 
     # ------------------------------------------------------------------ training forward
     def forward(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
-                timesteps: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                timesteps: Optional[torch.Tensor] = None, lengths=None) -> Dict[str, torch.Tensor]:
         """t ~ U{1..T} (drawn before the corruption uniforms, like the reference) ->
-        corruption -> denoiser -> masked CE (reference diffusion.py:129-167)."""
+        corruption -> denoiser -> masked CE (reference diffusion.py:129-167).
+
+        ``lengths`` (optional, host integers: last attended position + 1 per sequence) spares the training path
+        the device -> host copy it otherwise makes to lay out the packed rows (``skip_padded_rows``)."""
         B = input_ids.shape[0]
         dev = input_ids.device
         if timesteps is None:
             timesteps = torch.randint(1, self.num_steps + 1, (B,), device=dev)
         noisy_ids, mask_indicator = self.forward_process(input_ids, timesteps, attention_mask)
+        bb = self.backbone
+        if (self.skip_padded_rows and attention_mask is not None and torch.is_grad_enabled()
+                and getattr(bb, "compute_dtype", "bf16") == "bf16" and any(p.requires_grad for p in bb.parameters())):
+            from ..training.autograd import packed_training_loss
+            loss, logits = packed_training_loss(self, noisy_ids, bb._check_inputs(noisy_ids, timesteps), attention_mask,
+                                                input_ids, mask_indicator, lengths)
+            return {"loss": loss, "logits": logits, "noisy_ids": noisy_ids, "mask_indicator": mask_indicator,
+                    "timesteps": timesteps}
         logits = self.backbone(noisy_ids, timesteps, attention_mask)
         loss = self._compute_loss(logits, input_ids, mask_indicator, attention_mask)
         return {

@@ -104,6 +104,74 @@ def _to_bf16(x, out, drop=None, site=0):
                                               _s()), "bd_dropout_f32_to_bf16")
 
 
+class _PinnedRing:
+    """Small host -> device uploads that never block the host nor reuse a buffer a copy may still read."""
+
+    def __init__(self, slots=4):
+        self.slots, self.pos, self.ring = slots, 0, []
+
+    def upload_i32(self, arr, dev):
+        import numpy as np
+        n = int(arr.size)
+        if len(self.ring) < self.slots:
+            self.ring.append([torch.empty(max(n, 4096), dtype=torch.int32).pin_memory(), None])
+            slot = self.ring[-1]
+        else:
+            slot = self.ring[self.pos % self.slots]
+            self.pos += 1
+            if slot[1] is not None:
+                slot[1].synchronize()
+            if slot[0].numel() < n:
+                slot[0] = torch.empty(n, dtype=torch.int32).pin_memory()
+        slot[0][:n].copy_(torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int32)))
+        out = slot[0][:n].to(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        slot[1] = ev
+        return out
+
+
+_RING = _PinnedRing(slots=16)
+
+
+class RowPacking:
+    """Packed-row layout of one [B, L] batch: the rows behind each sequence's last attended position are left out
+    (they receive no attention as keys, carry no loss and no gradient). ``lengths`` (host integers, one per
+    sequence, = last attended position + 1) fixes the layout without a device round trip."""
+
+    def __init__(self, lengths, B, L, device, pad_to=128):
+        import numpy as np
+        ln = np.asarray(lengths, dtype=np.int64).reshape(-1)
+        if ln.size != B or (ln < 0).any() or (ln > L).any():
+            raise ValueError("RowPacking: lengths must hold one value in [0, L] per sequence")
+        cu = np.zeros(B + 1, dtype=np.int64)
+        np.cumsum(ln, out=cu[1:])
+        self.B, self.L = int(B), int(L)
+        self.n_real = int(cu[-1])
+        self.n_rows = max(pad_to, (self.n_real + pad_to - 1) // pad_to * pad_to)
+        self.max_len = int(ln.max()) if B else 0
+        self.cu = _RING.upload_i32(cu, device)
+        self.rowmap = torch.empty(self.n_rows, dtype=torch.int32, device=device)
+        _ck(_lib.lib().bd_build_rowmap(_lib.ptr(self.cu), self.B, self.L, self.n_rows, _lib.ptr(self.rowmap),
+                                       _lib.stream_handle()), "bd_build_rowmap")
+        self._gather = None
+
+    @staticmethod
+    def lengths_from_mask(attention_mask):
+        """Last attended position + 1 per sequence (one device -> host copy)."""
+        am = attention_mask != 0
+        L = am.shape[1]
+        last = L - am.flip(1).to(torch.int8).argmax(dim=1)
+        return torch.where(am.any(dim=1), last, torch.zeros_like(last)).cpu().numpy()
+
+    def gather_index(self):
+        """int64 index of each packed row's logical token (fillers point at token 0) and the filler mask."""
+        if self._gather is None:
+            rm = self.rowmap.to(torch.long)
+            self._gather = (rm.clamp(min=0), rm < 0)
+        return self._gather
+
+
 class _TrainWeights:
     """bf16 copies (and transposes for the data-gradient GEMMs) of the current parameters. Head sizes
     the attention kernels do not have (e.g. 48) are zero-padded to 32 / 64 / 128 (``dhp``); the q rows
@@ -225,14 +293,14 @@ def _train_weights(model):
 
 class _BackboneFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, ids, timesteps, keymask, mode, *params):
+    def forward(ctx, model, ids, timesteps, keymask, mode, pk, *params):
         """mode 0: logits [B, L, V] (the diffusion training step); mode 1: the final-norm hidden states
         [B, L, d] in fp32 (what get_hidden_states / get_pooled_output return to a property head that
         fine-tunes the last blocks, reference property_head.py:102-112)."""
         _enter()
         lib = _lib.lib()
         B, L = ids.shape
-        M = B * L
+        M = B * L if pk is None else pk.n_rows       # token rows every kernel below works on
         d, F, V, H = model.hidden_size, model.ffn_hidden_size, model.vocab_size, model.num_heads
         dev = ids.device
         bf = torch.bfloat16
@@ -241,10 +309,23 @@ class _BackboneFn(torch.autograd.Function):
         aw = tw.aw
         drop = model._next_dropout()          # None in eval mode or with dropout = 0
         x = torch.empty(M, d, device=dev)
-        _ck(lib.bd_embed_drop(_lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(model.token_embedding.weight),
-                              _lib.ptr(model.position_embedding.weight), _lib.ptr(model.timestep_embedding.weight),
-                              _lib.ptr(x), B, L, d, V, model.max_position_embeddings, model.num_diffusion_steps + 1,
-                              _dp(drop), 0, _s()), "bd_embed")
+        if pk is None:
+            _ck(lib.bd_embed_drop(_lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(model.token_embedding.weight),
+                                  _lib.ptr(model.position_embedding.weight), _lib.ptr(model.timestep_embedding.weight),
+                                  _lib.ptr(x), B, L, d, V, model.max_position_embeddings, model.num_diffusion_steps + 1,
+                                  _dp(drop), 0, _s()), "bd_embed")
+        else:
+            _ck(lib.bd_embed_rows(_lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(pk.rowmap),
+                                  _lib.ptr(model.token_embedding.weight), _lib.ptr(model.position_embedding.weight),
+                                  _lib.ptr(model.timestep_embedding.weight), _lib.ptr(x), M, L, d, V,
+                                  model.max_position_embeddings, model.num_diffusion_steps + 1, _dp(drop), 0, _s()),
+                "bd_embed_rows")
+        # attention outputs of all layers in one allocation: the filler rows of the packed layout belong to no
+        # sequence, the attention kernels never write them, and the weight-gradient GEMMs must not meet NaN bits there
+        n_l = len(model.layers)
+        att_all = torch.empty(n_l, M, aw, dtype=bf, device=dev)
+        if pk is not None and pk.n_rows > pk.n_real and n_l:
+            att_all[:, pk.n_real:].zero_()
         saved = []
         for li, (blk, w) in enumerate(zip(model.layers, tw.layers)):
             s = {"x_in": x}
@@ -253,10 +334,15 @@ class _BackboneFn(torch.autograd.Function):
             _ln(x, blk.norm1.weight, blk.norm1.bias, s["h1"], s["st1"], M, d, eps)
             s["qkv"] = torch.empty(M, 3 * aw, dtype=bf, device=dev)
             _gemm(s["h1"], w["wqkv"], w["bqkv"], s["qkv"], M, 3 * aw, 3 * aw, d, 3 * aw, 0)
-            s["att"] = torch.empty(M, aw, dtype=bf, device=dev)
+            s["att"] = att_all[li]
             s["lse"] = torch.empty(B, H, L, device=dev)
-            _ck(lib.bd_attention_fwd_drop(_lib.ptr(s["qkv"]), _lib.ptr(keymask), _lib.ptr(s["att"]), _lib.ptr(s["lse"]),
-                                          B, L, H, aw // H, _dp(drop), 4 * li + 1, _s()), "bd_attention_fwd")
+            if pk is None:
+                _ck(lib.bd_attention_fwd_drop(_lib.ptr(s["qkv"]), _lib.ptr(keymask), _lib.ptr(s["att"]), _lib.ptr(s["lse"]),
+                                              B, L, H, aw // H, _dp(drop), 4 * li + 1, _s()), "bd_attention_fwd")
+            else:
+                _ck(lib.bd_attention_fwd_varlen(_lib.ptr(s["qkv"]), _lib.ptr(keymask), _lib.ptr(s["att"]),
+                                                _lib.ptr(s["lse"]), _lib.ptr(pk.cu), B, L, H, aw // H, _dp(drop),
+                                                4 * li + 1, _s()), "bd_attention_fwd_varlen")
             x_mid = torch.empty(M, d, device=dev)
             _gemm(s["att"], w["wo"], blk.attn.out_proj.bias, x_mid, M, d, d, aw, d, 2, aux_in=x)
             s["x_mid"] = x_mid
@@ -273,17 +359,17 @@ class _BackboneFn(torch.autograd.Function):
             saved.append(s)
             x = x_out
         stf = torch.empty(M, 2, device=dev)
-        ctx.model, ctx.saved, ctx.tw, ctx.drop, ctx.mode = model, saved, tw, drop, int(mode)
+        ctx.model, ctx.saved, ctx.tw, ctx.drop, ctx.mode, ctx.pk = model, saved, tw, drop, int(mode), pk
         ctx.ids, ctx.timesteps, ctx.keymask = ids, timesteps, keymask
         if mode == 1:
-            hid = torch.empty(B, L, d, device=dev)
+            hid = torch.empty(B, L, d, device=dev) if pk is None else torch.empty(M, d, device=dev)
             _ck(lib.bd_layernorm(_lib.ptr(x), _lib.ptr(model.final_norm.weight), _lib.ptr(model.final_norm.bias), None,
                                  _lib.ptr(hid), _lib.ptr(stf), M, d, eps, _s()), "bd_layernorm")
             ctx.x_last, ctx.stf, ctx.hf = x, stf, None
             return hid
         hf = torch.empty(M, d, dtype=bf, device=dev)
         _ln(x, model.final_norm.weight, model.final_norm.bias, hf, stf, M, d, eps)
-        logits = torch.empty(B, L, V, device=dev)
+        logits = torch.empty(B, L, V, device=dev) if pk is None else torch.empty(M, V, device=dev)
         _gemm(hf, tw.wout, None, logits, M, tw.vpad, V, d, V, 3)
         ctx.x_last, ctx.stf, ctx.hf = x, stf, hf
         return logits
@@ -292,10 +378,10 @@ class _BackboneFn(torch.autograd.Function):
     def backward(ctx, dlogits):
         _enter()
         lib = _lib.lib()
-        model, tw, drop = ctx.model, ctx.tw, ctx.drop
+        model, tw, drop, pk = ctx.model, ctx.tw, ctx.drop, ctx.pk
         ids, timesteps, keymask = ctx.ids, ctx.timesteps, ctx.keymask
         B, L = ids.shape
-        M = B * L
+        M = B * L if pk is None else pk.n_rows
         d, F, V, H = model.hidden_size, model.ffn_hidden_size, model.vocab_size, model.num_heads
         dev = ids.device
         bf = torch.bfloat16
@@ -359,6 +445,9 @@ class _BackboneFn(torch.autograd.Function):
         dy2b = [torch.empty(M, d, dtype=bf, device=dev) for _ in range(nb)]                            # attention branch
         dub = [torch.empty(M, F, dtype=bf, device=dev) for _ in range(nb)]
         dqkvb = [torch.empty(M, 3 * aw, dtype=bf, device=dev) for _ in range(nb)]
+        if pk is not None and pk.n_rows > pk.n_real:
+            for t_ in dqkvb:                  # filler rows: never written by the attention backward, read by the wgrad
+                t_[pk.n_real:].zero_()
         pending, handed = [], {}
 
         def hand_over(li):
@@ -422,9 +511,14 @@ class _BackboneFn(torch.autograd.Function):
                 _wgrad(dy2, s["att"], tmp, M, d, aw, db=gbuf(a.out_proj.bias))
                 gbuf(a.out_proj.weight).view(d, H, dh).add_(tmp.view(d, H, dhp)[:, :, :dh])
             _gemm(dy2, w["woT"], None, datt, M, aw, aw, d, aw, 0)
-            _ck(lib.bd_attention_bwd_drop(_lib.ptr(s["qkv"]), _lib.ptr(keymask), _lib.ptr(s["att"]), _lib.ptr(datt),
-                                          _lib.ptr(s["lse"]), _lib.ptr(delta), _lib.ptr(dqkv), B, L, H, aw // H,
-                                          _dp(drop), 4 * li + 1, _s()), "bd_attention_bwd")
+            if pk is None:
+                _ck(lib.bd_attention_bwd_drop(_lib.ptr(s["qkv"]), _lib.ptr(keymask), _lib.ptr(s["att"]), _lib.ptr(datt),
+                                              _lib.ptr(s["lse"]), _lib.ptr(delta), _lib.ptr(dqkv), B, L, H, aw // H,
+                                              _dp(drop), 4 * li + 1, _s()), "bd_attention_bwd")
+            else:
+                _ck(lib.bd_attention_bwd_varlen(_lib.ptr(s["qkv"]), _lib.ptr(keymask), _lib.ptr(s["att"]), _lib.ptr(datt),
+                                                _lib.ptr(s["lse"]), _lib.ptr(delta), _lib.ptr(dqkv), _lib.ptr(pk.cu), B, L,
+                                                H, aw // H, _dp(drop), 4 * li + 1, _s()), "bd_attention_bwd_varlen")
             projs = (a.q_proj, a.k_proj, a.v_proj)
             if not padded:      # the three row segments of the stacked gradient, one launch
                 wgrad_side(li, dqkv, s["h1"], [gbuf(pr.weight) for pr in projs], 3 * aw, d, [gbuf(pr.bias) for pr in projs])
@@ -444,15 +538,22 @@ class _BackboneFn(torch.autograd.Function):
                 _TAIL_HOOK[0]()
         if need_embed and drop is not None:
             _ck(lib.bd_dropout_f32(_lib.ptr(dx), _lib.ptr(dx), M, d, _dp(drop), 0, _s()), "bd_dropout_f32")
-        if need_embed:
+        if need_embed and pk is None:
             _ck(lib.bd_embed_bwd(_lib.ptr(dx), _lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(gbuf(model.token_embedding.weight)),
                                  _lib.ptr(gbuf(model.position_embedding.weight)),
                                  _lib.ptr(gbuf(model.timestep_embedding.weight)), B, L, d, int(model.pad_token_id), V,
                                  model.max_position_embeddings, model.num_diffusion_steps + 1, _s()),
                 "bd_embed_bwd")
+        elif need_embed:
+            _ck(lib.bd_embed_bwd_varlen(_lib.ptr(dx), _lib.ptr(ids), _lib.ptr(timesteps),
+                                        _lib.ptr(gbuf(model.token_embedding.weight)),
+                                        _lib.ptr(gbuf(model.position_embedding.weight)),
+                                        _lib.ptr(gbuf(model.timestep_embedding.weight)), _lib.ptr(pk.cu), B, L, d,
+                                        int(model.pad_token_id), V, model.max_position_embeddings,
+                                        model.num_diffusion_steps + 1, _s()), "bd_embed_bwd_varlen")
         if side is not None:
             main.wait_stream(side)       # every gradient is complete before autograd / the optimizer go on
-        out = [None, None, None, None, None]
+        out = [None, None, None, None, None, None]
         for p in params:
             g = grads.get(p)
             out.append(g if (g is not None and p.requires_grad) else None)
@@ -460,8 +561,9 @@ class _BackboneFn(torch.autograd.Function):
         return tuple(out)
 
 
-def backbone_forward_train(model, input_ids, timesteps, attention_mask, hidden_states=False):
-    """Training forward: logits, or (``hidden_states=True``) the fp32 final-norm hidden states."""
+def backbone_forward_train(model, input_ids, timesteps, attention_mask, hidden_states=False, packing=None):
+    """Training forward: logits, or (``hidden_states=True``) the fp32 final-norm hidden states. With a
+    ``RowPacking`` the result holds the packed rows ([n_rows, V] or [n_rows, d]) instead of [B, L, .]."""
     _lib.require_device(input_ids, "DiffusionBackbone.forward")
     if model.hidden_size % 128 or model.ffn_hidden_size % 128:
         raise ValueError("bidiff training path needs hidden and ffn sizes that are multiples of 128")
@@ -471,7 +573,9 @@ def backbone_forward_train(model, input_ids, timesteps, attention_mask, hidden_s
     for p in model._params():
         if p.dtype != torch.float32 or not p.is_contiguous():
             raise RuntimeError("bidiff training path expects contiguous fp32 parameters")
-    return _BackboneFn.apply(model, ids, timesteps, keymask, 1 if hidden_states else 0, *model._params())
+    if packing is not None and (packing.B, packing.L) != tuple(ids.shape):
+        raise ValueError("RowPacking was built for another batch shape")
+    return _BackboneFn.apply(model, ids, timesteps, keymask, 1 if hidden_states else 0, packing, *model._params())
 
 
 class _MaskedCE(torch.autograd.Function):
@@ -512,3 +616,24 @@ def masked_cross_entropy(logits, targets, mask_indicator, attention_mask=None):
     if logits.dtype != torch.float32:
         logits = logits.float()
     return _MaskedCE.apply(logits, targets, mask_indicator, attention_mask)
+
+
+def packed_training_loss(diffusion, noisy_ids, timesteps, attention_mask, targets, mask_indicator, lengths=None):
+    """Denoiser + masked CE on the packed rows of the batch. Returns (loss, logits [B, L, V]): the loss and its
+    gradients equal the padded computation's (padded rows contribute to neither); the returned logits are a
+    detached copy with zeros at the rows that were left out."""
+    backbone = diffusion.backbone
+    B, L = noisy_ids.shape
+    if lengths is None:
+        lengths = RowPacking.lengths_from_mask(attention_mask)
+    pk = RowPacking(lengths, B, L, noisy_ids.device)
+    logits_p = backbone_forward_train(backbone, noisy_ids, timesteps, attention_mask, packing=pk)
+    idx, filler = pk.gather_index()
+    tg = targets.reshape(-1)[idx]
+    ind = mask_indicator.reshape(-1)[idx] & ~filler
+    am = attention_mask.reshape(-1)[idx]
+    loss = masked_cross_entropy(logits_p, tg, ind, am)
+    with torch.no_grad():
+        full = torch.zeros(B * L, logits_p.shape[-1], device=logits_p.device, dtype=logits_p.dtype)
+        full.index_copy_(0, idx[:pk.n_real], logits_p.detach()[:pk.n_real])
+    return loss, full.view(B, L, -1)

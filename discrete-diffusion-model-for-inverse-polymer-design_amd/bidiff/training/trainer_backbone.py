@@ -117,10 +117,12 @@ class BackboneTrainer:
             dist.barrier()
 
     # ------------------------------------------------------------------ the hot step
-    def train_step_device(self, input_ids, attention_mask, should_step: bool = True):
+    def train_step_device(self, input_ids, attention_mask, should_step: bool = True, lengths=None):
         """One micro-batch on device tensors; returns the (unscaled) loss as a device scalar
-        without synchronising the host (reference _train_step, trainer_backbone.py:414-457)."""
-        out = self.model(input_ids, attention_mask)
+        without synchronising the host (reference _train_step, trainer_backbone.py:414-457).
+        ``lengths``: optional host integers (tokens per sequence) for the packed-row layout."""
+        out = self.model(input_ids, attention_mask, lengths=lengths) if lengths is not None \
+            else self.model(input_ids, attention_mask)
         loss = out["loss"] / self.grad_accum_steps
         if should_step and self._exchange is not None:
             self._exchange.arm()
@@ -141,7 +143,7 @@ class BackboneTrainer:
     def _train_step(self, batch, should_step: bool) -> float:
         ids = batch["input_ids"].to(self.device)
         am = batch["attention_mask"].to(self.device)
-        return float(self.train_step_device(ids, am, should_step).item())
+        return float(self.train_step_device(ids, am, should_step, lengths=batch.get("lengths")).item())
 
     def _validate(self) -> float:
         self.model.eval()

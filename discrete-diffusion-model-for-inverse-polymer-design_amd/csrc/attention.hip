@@ -41,7 +41,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
                                                           const unsigned char* __restrict__ keymask,
                                                           unsigned short* __restrict__ out,
                                                           float* __restrict__ lse_out,
-                                                          int L, int H, float scale, bd_drop_args drop) {
+                                                          int Ls, int H, float scale, bd_drop_args drop,
+                                                          const int* __restrict__ cu) {
+  // Ls = row stride of the [B, Ls] key mask, of the [B, H, Ls] log-sum-exp and of the dropout rows. With cu
+  // (packed rows: sequence b occupies rows cu[b] .. cu[b + 1] - 1 of qkv / out) L is that sequence's own length.
+  const int L = cu ? cu[blockIdx.z + 1] - cu[blockIdx.z] : Ls;
+  if ((int)blockIdx.x * (64 * QB) >= L) return;            // no query of this sequence in the block (uniform)
+  const size_t tb = cu ? (size_t)cu[blockIdx.z] : (size_t)blockIdx.z * Ls;   // first row of the sequence
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KT * ROWB + KT];
   unsigned char* const Ks = smem;
   unsigned char* const Vs = smem + KT * ROWB;
@@ -63,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     int qr = q0 + 16 * qb + c; qr = qr < L ? qr : L - 1;
-    const unsigned short* qp = qkv + ((size_t)b * L + qr) * row3 + (size_t)h * DH + 8 * g;
+    const unsigned short* qp = qkv + (tb + qr) * row3 + (size_t)h * DH + 8 * g;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[qb][ks] = *(const bf16x8*)(qp + 32 * ks);
   }
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
     if (tid < KT) {
       const int key = kt0 + tid;
       unsigned char mv = 0;
-      if (key < L) mv = keymask ? (keymask[(size_t)b * L + key] != 0) : 1;
+      if (key < L) mv = keymask ? (keymask[(size_t)b * Ls + key] != 0) : 1;
       Ms[tid] = mv;
     }
     __syncthreads();
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
       const int key = kt0 + row;
       u32x4 kv = (u32x4){0u, 0u, 0u, 0u}, vv = (u32x4){0u, 0u, 0u, 0u};
       if (key < L) {
-        const unsigned short* base = qkv + ((size_t)b * L + key) * row3 + (size_t)h * DH + ch * 8;
+        const unsigned short* base = qkv + (tb + key) * row3 + (size_t)h * DH + ch * 8;
         kv = *(const u32x4*)(base + d);
         vv = *(const u32x4*)(base + 2 * d);
       }
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
 
       // ---- dropout of the probabilities (the normaliser l_run keeps every visible key)
       if (DROP) {
-        const uint32_t prow = (uint32_t)(((size_t)b * H + h) * L + (q0 + 16 * qb + c));
+        const uint32_t prow = (uint32_t)(((size_t)b * H + h) * Ls + (q0 + 16 * qb + c));
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {      // tiles 2 s4, 2 s4 + 1 = keys key0 .. key0 + 7: one block
           const int key0 = kt0 + 32 * s4 + 8 * g;
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
     const int qrow = q0 + 16 * qb + c;
     const float inv = l_run[qb] > 0.f ? 1.0f / l_run[qb] : 0.f;
     if (qrow < L) {
-      unsigned short* op = out + ((size_t)b * L + qrow) * d + (size_t)h * DH + 4 * g;
+      unsigned short* op = out + (tb + qrow) * d + (size_t)h * DH + 4 * g;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         u32x2 w;
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
         *(u32x2*)(op + 16 * dt) = w;
       }
       if (lse_out != nullptr && g == 0)
-        lse_out[((size_t)b * H + h) * L + qrow] = l_run[qb] > 0.f ? (m_run[qb] + __logf(l_run[qb])) : -INFINITY;
+        lse_out[((size_t)b * H + h) * Ls + qrow] = l_run[qb] > 0.f ? (m_run[qb] + __logf(l_run[qb])) : -INFINITY;
     }
   }
 }
@@ -243,22 +249,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
 // out [B*L, H*DH] bf16, lse (optional) [B, H, L] fp32 log-sum-exp of the scaled scores.
 template <int DH>
 static void launch_attn_fwd(hipStream_t s, const void* qkv, const unsigned char* keymask, void* out, float* lse, int B,
-                            int L, int H, float scale, const bd_drop_args& da) {
+                            int L, int H, float scale, const bd_drop_args& da, const int* cu) {
   const unsigned short* q = (const unsigned short*)qkv;
   unsigned short* o = (unsigned short*)out;
   if (L > 64) {      // two query blocks per wave: 128 queries per workgroup
     dim3 grid((L + 127) / 128, H, B);
-    if (da.thr != 0u) hipLaunchKernelGGL((attn_fwd_kernel<DH, true, 2>), grid, dim3(256), 0, s, q, keymask, o, lse, L, H, scale, da);
-    else hipLaunchKernelGGL((attn_fwd_kernel<DH, false, 2>), grid, dim3(256), 0, s, q, keymask, o, lse, L, H, scale, da);
+    if (da.thr != 0u) hipLaunchKernelGGL((attn_fwd_kernel<DH, true, 2>), grid, dim3(256), 0, s, q, keymask, o, lse, L, H, scale, da, cu);
+    else hipLaunchKernelGGL((attn_fwd_kernel<DH, false, 2>), grid, dim3(256), 0, s, q, keymask, o, lse, L, H, scale, da, cu);
   } else {
     dim3 grid((L + 63) / 64, H, B);
-    if (da.thr != 0u) hipLaunchKernelGGL((attn_fwd_kernel<DH, true, 1>), grid, dim3(256), 0, s, q, keymask, o, lse, L, H, scale, da);
-    else hipLaunchKernelGGL((attn_fwd_kernel<DH, false, 1>), grid, dim3(256), 0, s, q, keymask, o, lse, L, H, scale, da);
+    if (da.thr != 0u) hipLaunchKernelGGL((attn_fwd_kernel<DH, true, 1>), grid, dim3(256), 0, s, q, keymask, o, lse, L, H, scale, da, cu);
+    else hipLaunchKernelGGL((attn_fwd_kernel<DH, false, 1>), grid, dim3(256), 0, s, q, keymask, o, lse, L, H, scale, da, cu);
   }
 }
 
-extern "C" int bd_attention_fwd_drop(const void* qkv, const unsigned char* keymask, void* out, float* lse, int B, int L,
-                                     int H, int head_dim, const bd_dropout* drop, unsigned site, void* stream) {
+static int attention_fwd_impl(const void* qkv, const unsigned char* keymask, void* out, float* lse, const int* cu,
+                              int B, int L, int H, int head_dim, const bd_dropout* drop, unsigned site, void* stream) {
   BD_REQUIRE(qkv && out, "bd_attention_fwd: null operand");
   BD_REQUIRE(B > 0 && L > 0 && H > 0, "bd_attention_fwd: empty shape");
   BD_REQUIRE(B <= 65535 && H <= 65535, "bd_attention_fwd: B and H must be <= 65535");
@@ -269,13 +275,25 @@ extern "C" int bd_attention_fwd_drop(const void* qkv, const unsigned char* keyma
   const float scale = 1.0f / sqrtf((float)head_dim);
   hipStream_t s = (hipStream_t)stream;
   switch (head_dim) {
-    case 32: launch_attn_fwd<32>(s, qkv, keymask, out, lse, B, L, H, scale, da); break;
-    case 64: launch_attn_fwd<64>(s, qkv, keymask, out, lse, B, L, H, scale, da); break;
-    case 128: launch_attn_fwd<128>(s, qkv, keymask, out, lse, B, L, H, scale, da); break;
+    case 32: launch_attn_fwd<32>(s, qkv, keymask, out, lse, B, L, H, scale, da, cu); break;
+    case 64: launch_attn_fwd<64>(s, qkv, keymask, out, lse, B, L, H, scale, da, cu); break;
+    case 128: launch_attn_fwd<128>(s, qkv, keymask, out, lse, B, L, H, scale, da, cu); break;
     default:
       return bd_fail(BD_ERR_UNSUPPORTED, "bd_attention_fwd: head_dim %d not in {32, 64, 128}", head_dim);
   }
   return bd_check_launch("bd_attention_fwd");
+}
+
+extern "C" int bd_attention_fwd_drop(const void* qkv, const unsigned char* keymask, void* out, float* lse, int B, int L,
+                                     int H, int head_dim, const bd_dropout* drop, unsigned site, void* stream) {
+  return attention_fwd_impl(qkv, keymask, out, lse, nullptr, B, L, H, head_dim, drop, site, stream);
+}
+
+extern "C" int bd_attention_fwd_varlen(const void* qkv, const unsigned char* keymask, void* out, float* lse,
+                                       const int* cu_seqlens, int B, int L, int H, int head_dim, const bd_dropout* drop,
+                                       unsigned site, void* stream) {
+  BD_REQUIRE(cu_seqlens != nullptr, "bd_attention_fwd_varlen: null cu_seqlens");
+  return attention_fwd_impl(qkv, keymask, out, lse, cu_seqlens, B, L, H, head_dim, drop, site, stream);
 }
 
 extern "C" int bd_attention_fwd(const void* qkv, const unsigned char* keymask, void* out,

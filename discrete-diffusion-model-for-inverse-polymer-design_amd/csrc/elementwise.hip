@@ -16,12 +16,20 @@ __global__ __launch_bounds__(256) void embed_kernel(const long long* __restrict_
                                                     const float* __restrict__ pos,
                                                     const float* __restrict__ tim,
                                                     float* __restrict__ x, int M, int L, int d,
-                                                    int vocab, int n_timesteps, bd_drop_args drop) {
+                                                    int vocab, int n_timesteps, bd_drop_args drop,
+                                                    const int* __restrict__ rowmap) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
-  const long long id = ids[row];
-  const long long t = tsteps[row / L];
+  // packed rows: row holds logical token rowmap[row] = b * L + l of the [B, L] batch, or nothing (< 0: zeros)
+  const int lrow = rowmap ? rowmap[row] : row;
+  if (lrow < 0) {
+    f32x4* o = (f32x4*)(x + (size_t)row * d);
+    for (int i = lane; i < d / 4; i += 64) { f32x4 r; r[0] = 0.f; r[1] = 0.f; r[2] = 0.f; r[3] = 0.f; o[i] = r; }
+    return;
+  }
+  const long long id = ids[lrow];
+  const long long t = tsteps[lrow / L];
   if (id < 0 || id >= vocab || t < 0 || t >= n_timesteps) {
     // an index outside its table (nn.Embedding raises there): never read past the table, and make the
     // row NaN so that the logits and the loss of this batch are visibly invalid
@@ -31,7 +39,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const long long* __restrict_
     return;
   }
   const f32x4* a = (const f32x4*)(tok + (size_t)id * d);
-  const f32x4* b = (const f32x4*)(pos + (size_t)(row % L) * d);
+  const f32x4* b = (const f32x4*)(pos + (size_t)(lrow % L) * d);
   const f32x4* c = (const f32x4*)(tim + (size_t)t * d);
   f32x4* o = (f32x4*)(x + (size_t)row * d);
   for (int i = lane; i < d / 4; i += 64) {
@@ -373,8 +381,43 @@ extern "C" int bd_embed_drop(const long long* ids, const long long* timesteps, c
   BD_REQUIRE(M < (1ll << 31), "bd_embed: too many tokens");
   bd_prof_scope prof(stream, (double)M * (d * 4.0 + 8.0), BD_PROF_EMBED);
   hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ids,
-                     timesteps, tok_emb, pos_emb, time_emb, x, (int)M, L, d, vocab, n_timesteps, da);
+                     timesteps, tok_emb, pos_emb, time_emb, x, (int)M, L, d, vocab, n_timesteps, da, (const int*)nullptr);
   return bd_check_launch("bd_embed");
+}
+
+extern "C" int bd_embed_rows(const long long* ids, const long long* timesteps, const int* rowmap, const float* tok_emb,
+                             const float* pos_emb, const float* time_emb, float* x, int n_rows, int L, int d, int vocab,
+                             int max_pos, int n_timesteps, const bd_dropout* drop, unsigned site, void* stream) {
+  BD_REQUIRE(ids && timesteps && rowmap && tok_emb && pos_emb && time_emb && x, "bd_embed_rows: null operand");
+  BD_REQUIRE(vocab > 0 && n_timesteps > 0, "bd_embed_rows: empty table");
+  BD_REQUIRE(L <= max_pos, "bd_embed_rows: sequence length %d exceeds max_position_embeddings %d", L, max_pos);
+  bd_drop_args da;
+  BD_REQUIRE(bd_drop_make(drop, site, &da), "bd_embed_rows: dropout p=%g outside [0, 1)", (double)drop->p);
+  BD_REQUIRE(n_rows > 0 && L > 0 && d > 0 && d % 4 == 0, "bd_embed_rows: bad shape rows=%d L=%d d=%d", n_rows, L, d);
+  bd_prof_scope prof(stream, (double)n_rows * (d * 4.0 + 12.0), BD_PROF_EMBED);
+  hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ids, timesteps,
+                     tok_emb, pos_emb, time_emb, x, n_rows, L, d, vocab, n_timesteps, da, rowmap);
+  return bd_check_launch("bd_embed_rows");
+}
+
+// rowmap[r] = b * L + (r - cu[b]) for the sequence b whose packed rows contain r, -1 for rows >= cu[B]
+static __global__ __launch_bounds__(256) void rowmap_kernel(const int* __restrict__ cu, int B, int L, int n_rows,
+                                                     int* __restrict__ rowmap) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_rows) return;
+  int lo = 0, hi = B;                 // largest b with cu[b] <= r
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (cu[mid] <= r) lo = mid; else hi = mid;
+  }
+  rowmap[r] = r < cu[B] ? lo * L + (r - cu[lo]) : -1;
+}
+
+extern "C" int bd_build_rowmap(const int* cu_seqlens, int B, int L, int n_rows, int* rowmap, void* stream) {
+  BD_REQUIRE(cu_seqlens && rowmap && B > 0 && L > 0 && n_rows > 0, "bd_build_rowmap: bad argument");
+  hipLaunchKernelGGL(rowmap_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cu_seqlens, B,
+                     L, n_rows, rowmap);
+  return bd_check_launch("bd_build_rowmap");
 }
 
 extern "C" int bd_layernorm(const float* x, const float* gamma, const float* beta, void* out_bf16,

@@ -107,8 +107,10 @@ __global__ __launch_bounds__(512) void layernorm_bwd_kernel(const unsigned short
                                                             const float* dres, float* dx,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             int M, int d, unsigned short* __restrict__ dx_bf16,
-                                                            bd_drop_args drop) {
-  constexpr int RPW = 16;
+                                                            bd_drop_args drop, int rpw) {
+  // rpw rows per wave (host: enough workgroups to fill the chip), walked two at a time so that the second row's
+  // loads and reductions overlap the first's (a wave that handles its rows one after another spends its time
+  // waiting: each row is a load, two dependent wave reductions and a store)
   extern __shared__ float red[];   // [2][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = d / 4;
@@ -122,60 +124,76 @@ __global__ __launch_bounds__(512) void layernorm_bwd_kernel(const unsigned short
     ag[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     ab[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  const int row0 = (blockIdx.x * 8 + wave) * RPW;
-  for (int rr = 0; rr < RPW; ++rr) {
-    const int row = row0 + rr;
-    if (row >= M) break;
-    const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
-    f32x4 xh[NV], g[NV];
-    float s1 = 0.f, s2 = 0.f;
+  const int row0 = (blockIdx.x * 8 + wave) * rpw;
+  for (int rr = 0; rr < rpw; rr += 2) {
+    f32x4 xh[2][NV], g[2][NV];
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, rstd[2] = {0.f, 0.f};
+    bool on[2];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int i = lane + 64 * j;
-      if (i < nv) {
-        const f32x4 xv = ((const f32x4*)(x + (size_t)row * d))[i];
-        const u32x2 dw = *(const u32x2*)(dy + (size_t)row * d + 4 * i);
-        f32x4 dv;
-        dv[0] = __uint_as_float(dw[0] << 16); dv[1] = __uint_as_float(dw[0] & 0xffff0000u);
-        dv[2] = __uint_as_float(dw[1] << 16); dv[3] = __uint_as_float(dw[1] & 0xffff0000u);
+    for (int u = 0; u < 2; ++u) {
+      const int row = row0 + rr + u;
+      on[u] = rr + u < rpw && row < M;
+      if (!on[u]) continue;
+      const float mean = stats[2 * (size_t)row];
+      rstd[u] = stats[2 * (size_t)row + 1];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          xh[j][e] = (xv[e] - mean) * rstd;
-          g[j][e] = dv[e] * gm[j][e];
-          s1 += g[j][e];
-          s2 += g[j][e] * xh[j][e];
-          ag[j][e] += dv[e] * xh[j][e];
-          ab[j][e] += dv[e];
+      for (int j = 0; j < NV; ++j) {
+        const int i = lane + 64 * j;
+        if (i < nv) {
+          const f32x4 xv = ((const f32x4*)(x + (size_t)row * d))[i];
+          const u32x2 dw = *(const u32x2*)(dy + (size_t)row * d + 4 * i);
+          f32x4 dv;
+          dv[0] = __uint_as_float(dw[0] << 16); dv[1] = __uint_as_float(dw[0] & 0xffff0000u);
+          dv[2] = __uint_as_float(dw[1] << 16); dv[3] = __uint_as_float(dw[1] & 0xffff0000u);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            xh[u][j][e] = (xv[e] - mean) * rstd[u];
+            g[u][j][e] = dv[e] * gm[j][e];
+            s1[u] += g[u][j][e];
+            s2[u] += g[u][j][e] * xh[u][j][e];
+            ag[j][e] += dv[e] * xh[u][j][e];
+            ab[j][e] += dv[e];
+          }
+        } else {
+          xh[u][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          g[u][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-      } else {
-        xh[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        g[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
     }
-    s1 = bd_wave_sum(s1) / (float)d;
-    s2 = bd_wave_sum(s2) / (float)d;
+    // the four wave sums of the two rows, interleaved
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int i = lane + 64 * j;
-      if (i < nv) {
-        f32x4 o;
+    for (int o = 32; o > 0; o >>= 1) {
+      s1[0] += __shfl_xor(s1[0], o, 64); s2[0] += __shfl_xor(s2[0], o, 64);
+      s1[1] += __shfl_xor(s1[1], o, 64); s2[1] += __shfl_xor(s2[1], o, 64);
+    }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rstd * (g[j][e] - s1 - xh[j][e] * s2);
-        if (dres != nullptr) {
-          const f32x4 r = ((const f32x4*)(dres + (size_t)row * d))[i];
-          o[0] += r[0]; o[1] += r[1]; o[2] += r[2]; o[3] += r[3];
-        }
-        ((f32x4*)(dx + (size_t)row * d))[i] = o;
-        if (dx_bf16 != nullptr) {      // the next branch's incoming gradient: bf16 copy, optionally dropped
-          if (drop.thr != 0u) {
-            const bd_philox_out w = bd_drop_block(drop, (uint32_t)row, (uint32_t)(i >> 1));
-            const int j0 = 4 * (i & 1);
+    for (int u = 0; u < 2; ++u) {
+      if (!on[u]) continue;
+      const int row = row0 + rr + u;
+      const float m1 = s1[u] / (float)d, m2 = s2[u] / (float)d;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] *= bd_drop_factor(drop, w, j0 + e);
+      for (int j = 0; j < NV; ++j) {
+        const int i = lane + 64 * j;
+        if (i < nv) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = rstd[u] * (g[u][j][e] - m1 - xh[u][j][e] * m2);
+          if (dres != nullptr) {
+            const f32x4 r = ((const f32x4*)(dres + (size_t)row * d))[i];
+            o[0] += r[0]; o[1] += r[1]; o[2] += r[2]; o[3] += r[3];
           }
-          u32x2 pk;
-          pk[0] = bd_pack_bf16x2(o[0], o[1]); pk[1] = bd_pack_bf16x2(o[2], o[3]);
-          *(u32x2*)(dx_bf16 + (size_t)row * d + 4 * i) = pk;
+          ((f32x4*)(dx + (size_t)row * d))[i] = o;
+          if (dx_bf16 != nullptr) {      // the next branch's incoming gradient: bf16 copy, optionally dropped
+            if (drop.thr != 0u) {
+              const bd_philox_out w = bd_drop_block(drop, (uint32_t)row, (uint32_t)(i >> 1));
+              const int j0 = 4 * (i & 1);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] *= bd_drop_factor(drop, w, j0 + e);
+            }
+            u32x2 pk;
+            pk[0] = bd_pack_bf16x2(o[0], o[1]); pk[1] = bd_pack_bf16x2(o[2], o[3]);
+            *(u32x2*)(dx_bf16 + (size_t)row * d + 4 * i) = pk;
+          }
         }
       }
     }
@@ -523,8 +541,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned shor
                                                              const unsigned short* __restrict__ dO,
                                                              const float* __restrict__ lse,
                                                              float* __restrict__ delta,
-                                                             unsigned short* __restrict__ dqkv, int L, int H,
-                                                             float scale, bd_drop_args drop) {
+                                                             unsigned short* __restrict__ dqkv, int Ls, int H,
+                                                             float scale, bd_drop_args drop, const int* __restrict__ cu) {
+  // Ls = row stride of the [B, Ls] key mask, of lse / delta [B, H, Ls] and of the dropout rows; with cu (packed rows:
+  // sequence b = rows cu[b] .. cu[b + 1] - 1 of qkv / O / dO / dqkv) L is the sequence's own length
+  const int L = cu ? cu[blockIdx.z + 1] - cu[blockIdx.z] : Ls;
+  if ((int)blockIdx.x * 64 >= L) return;
+  const size_t tb = cu ? (size_t)cu[blockIdx.z] : (size_t)blockIdx.z * Ls;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * AT * AROW + AT];
   unsigned char* const Ks = smem;
   unsigned char* const Vs = smem + AT * AROW;
@@ -539,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned shor
   int qr = q0 + c;
   const bool qok = qr < L;
   qr = qok ? qr : L - 1;
-  const size_t tok = (size_t)b * L + qr;
+  const size_t tok = tb + qr;
 
   bf16x8 qf[KS], dof[KS];
   float dl = 0.f;
@@ -558,13 +581,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned shor
   }
   dl += __shfl_xor(dl, 16, 64);
   dl += __shfl_xor(dl, 32, 64);
-  const float lq = lse[((size_t)b * H + h) * L + qr];
+  const float lq = lse[((size_t)b * H + h) * Ls + qr];
   // delta_i = sum_j P_ij dP_ij. With all keys in one tile (L <= 128) it is summed from the very P and dP that
   // form dS below, in fp32, so that sum_j dS_ij = 0 holds to rounding: rowsum(dO * O) from the bf16-rounded O
   // misses that by 2^-9 of |dO||O|, which is as large as dS itself when the attention is nearly uniform (the
   // q / k gradients of a freshly initialised model came out 13 % off). Longer sequences keep rowsum(dO * O).
   const bool one_tile = L <= AT;
-  if (!one_tile && qok && g == 0) delta[((size_t)b * H + h) * L + qr] = dl;
+  if (!one_tile && qok && g == 0) delta[((size_t)b * H + h) * Ls + qr] = dl;
 
   f32x4 acc[DT];
 #pragma unroll
@@ -575,7 +598,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned shor
     if (kt0 > 0) __syncthreads();
     if (tid < AT) {
       const int key = kt0 + tid;
-      Ms[tid] = key < L ? (keymask ? (keymask[(size_t)b * L + key] != 0) : 1) : 0;
+      Ms[tid] = key < L ? (keymask ? (keymask[(size_t)b * Ls + key] != 0) : 1) : 0;
     }
     __syncthreads();
     // 32-key groups without a visible key have P = 0 and dS = 0: not loaded, not multiplied
@@ -585,8 +608,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned shor
       const u32x4 m0 = *(const u32x4*)(Ms + 32 * s4), m1 = *(const u32x4*)(Ms + 32 * s4 + 16);
       if ((m0[0] | m0[1] | m0[2] | m0[3] | m1[0] | m1[1] | m1[2] | m1[3]) != 0u) live |= 1u << s4;
     }
-    stage_rows<DH>(Ks, qkv + (size_t)b * L * row3 + d + (size_t)h * DH, row3, kt0, L, tid, live);
-    stage_rows<DH>(Vs, qkv + (size_t)b * L * row3 + 2 * d + (size_t)h * DH, row3, kt0, L, tid, live);
+    stage_rows<DH>(Ks, qkv + tb * row3 + d + (size_t)h * DH, row3, kt0, L, tid, live);
+    stage_rows<DH>(Vs, qkv + tb * row3 + 2 * d + (size_t)h * DH, row3, kt0, L, tid, live);
     __syncthreads();
     float pv[4][8], dv[4][8];
     float psum = 0.f;
@@ -609,7 +632,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned shor
         const int kb = 32 * s4 + 8 * g + 4 * half;
         const unsigned int m4 = *(const unsigned int*)(Ms + kb);
         if (DROP) {   // dP = (dO V^T) * keep / (1 - p)
-          const bd_philox_out w = bd_drop_block(drop, (uint32_t)(((size_t)b * H + h) * L + qr), (uint32_t)((kt0 + kb) >> 3));
+          const bd_philox_out w = bd_drop_block(drop, (uint32_t)(((size_t)b * H + h) * Ls + qr), (uint32_t)((kt0 + kb) >> 3));
 #pragma unroll
           for (int r = 0; r < 4; ++r) dp[r] *= bd_drop_factor(drop, w, 4 * half + r);
         }
@@ -627,7 +650,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned shor
       psum += __shfl_xor(psum, 16, 64);
       psum += __shfl_xor(psum, 32, 64);
       dl = psum;
-      if (qok && g == 0) delta[((size_t)b * H + h) * L + qr] = dl;
+      if (qok && g == 0) delta[((size_t)b * H + h) * Ls + qr] = dl;
     }
     bf16x8 dsf[4];
 #pragma unroll
@@ -668,13 +691,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const unsigned sho
                                                               const unsigned short* __restrict__ dO,
                                                               const float* __restrict__ lse,
                                                               const float* __restrict__ delta,
-                                                              unsigned short* __restrict__ dqkv, int L, int H,
-                                                              float scale, bd_drop_args drop) {
+                                                              unsigned short* __restrict__ dqkv, int Ls, int H,
+                                                              float scale, bd_drop_args drop, const int* __restrict__ cu) {
+  const int L = cu ? cu[blockIdx.z + 1] - cu[blockIdx.z] : Ls;      // see attn_bwd_dq_kernel
+  if ((int)blockIdx.x * 64 >= L) return;
+  const size_t tb = cu ? (size_t)cu[blockIdx.z] : (size_t)blockIdx.z * Ls;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * AT * AROW + 2 * AT * 4];
   unsigned char* const Qs = smem;
   unsigned char* const Ds = smem + AT * AROW;
-  float* const Ls = (float*)(smem + 2 * AT * AROW);
-  float* const Dl = Ls + AT;
+  float* const Lq = (float*)(smem + 2 * AT * AROW);
+  float* const Dl = Lq + AT;
   constexpr int KS = DH / 32, DT = DH / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
@@ -685,8 +711,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const unsigned sho
   int kr = k0 + c;
   const bool kok = kr < L;
   kr = kok ? kr : L - 1;
-  const size_t tok = (size_t)b * L + kr;
-  const bool vis = kok && (keymask ? keymask[tok] != 0 : true);
+  const size_t tok = tb + kr;
+  const bool vis = kok && (keymask ? keymask[(size_t)b * Ls + kr] != 0 : true);
   if (!__syncthreads_or(vis)) {       // no visible key in this workgroup: dK = dV = 0
     if (kok) {
       unsigned short* op = dqkv + tok * row3 + d + (size_t)h * DH + 4 * g;
@@ -716,12 +742,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const unsigned sho
 
   for (int qt0 = 0; qt0 < L; qt0 += AT) {
     if (qt0 > 0) __syncthreads();
-    stage_rows<DH>(Qs, qkv + (size_t)b * L * row3 + (size_t)h * DH, row3, qt0, L, tid);
-    stage_rows<DH>(Ds, dO + (size_t)b * L * d + (size_t)h * DH, (size_t)d, qt0, L, tid);
+    stage_rows<DH>(Qs, qkv + tb * row3 + (size_t)h * DH, row3, qt0, L, tid);
+    stage_rows<DH>(Ds, dO + tb * d + (size_t)h * DH, (size_t)d, qt0, L, tid);
     if (tid < AT) {
       const int q = qt0 + tid;
-      Ls[tid] = q < L ? lse[((size_t)b * H + h) * L + q] : INFINITY;
-      Dl[tid] = q < L ? delta[((size_t)b * H + h) * L + q] : 0.f;
+      Lq[tid] = q < L ? lse[((size_t)b * H + h) * Ls + q] : INFINITY;
+      Dl[tid] = q < L ? delta[((size_t)b * H + h) * Ls + q] : 0.f;
     }
     __syncthreads();
     if (!wave_live) continue;
@@ -729,7 +755,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const unsigned sho
     // per query (the block holds eight neighbouring KEYS); a rolled loop keeps the registers free
     uint32_t keepbits = 0u;
     if (DROP) {
-      const uint32_t prow0 = (uint32_t)(((size_t)b * H + h) * L + qt0 + 8 * g);
+      const uint32_t prow0 = (uint32_t)(((size_t)b * H + h) * Ls + qt0 + 8 * g);
 #pragma nounroll
       for (int i = 0; i < 32; ++i) {
         const bd_philox_out w = bd_drop_block(drop, prow0 + 32 * (i >> 3) + (i & 7), (uint32_t)(kr >> 3));
@@ -756,7 +782,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const unsigned sho
         const int qb = 32 * s4 + 8 * g + 4 * half;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float lq = Ls[qb + r];
+          const float lq = Lq[qb + r];
           const bool on = vis && lq > -INFINITY && lq < INFINITY;
           const float p = on ? __expf(s[r] * scale - lq) : 0.f;
           const float z = !DROP ? 1.0f : (((keepbits >> (8 * s4 + 4 * half + r)) & 1u) ? drop.scale : 0.f);
@@ -809,16 +835,18 @@ constexpr int EB_MAXL = 1024;    // longest sequence of embed_bwd_seq_kernel
 
 __global__ __launch_bounds__(256) void embed_bwd_seq_kernel(const float* __restrict__ dx, const long long* __restrict__ ids,
                                                             const long long* __restrict__ tsteps, float* __restrict__ dtok,
-                                                            float* __restrict__ dtim, int L, int d, int pad_id,
-                                                            int vocab, int n_timesteps) {
+                                                            float* __restrict__ dtim, int Ls, int d, int pad_id,
+                                                            int vocab, int n_timesteps, const int* __restrict__ cu) {
+  // packed rows (cu given): sequence b = rows cu[b] .. cu[b + 1] - 1 of dx, its ids at ids[b * Ls + l]
+  const int L = cu ? cu[blockIdx.x + 1] - cu[blockIdx.x] : Ls;
   // Rows of one sequence sorted by token id (rank sort in LDS), so that rows sharing a token - the mask token is
   // half of a corrupted sequence - are summed in registers and reach the token's row as one atomic per sequence:
   // same-address atomics retire one after another (about 36 ns each), 5000 mask rows of a batch took 180 us.
   __shared__ int sid[EB_MAXL];
   __shared__ short sord[EB_MAXL];
   const int b = blockIdx.x;
-  const float* g = dx + (size_t)b * L * d;
-  for (int l = threadIdx.x; l < L; l += 256) sid[l] = (int)ids[(size_t)b * L + l];
+  const float* g = dx + (cu ? (size_t)cu[b] : (size_t)b * Ls) * d;
+  for (int l = threadIdx.x; l < L; l += 256) sid[l] = (int)ids[(size_t)b * Ls + l];
   __syncthreads();
   for (int l = threadIdx.x; l < L; l += 256) {
     const int mine = sid[l];
@@ -853,6 +881,22 @@ __global__ __launch_bounds__(256) void embed_bwd_seq_kernel(const float* __restr
     }
     if (run != 0.f && run_id != pad_id && run_id >= 0 && run_id < vocab) atomicAdd(dtok + (size_t)run_id * d + i, run);
     if (tsum != 0.f && ts_ok) atomicAdd(c + i, tsum);
+  }
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_pos_varlen_kernel(const float* __restrict__ dx, float* __restrict__ dpos,
+                                                                   const int* __restrict__ cu, int B, int d) {
+  // packed rows: position l of sequence b is row cu[b] + l when l < its length
+  const int l = blockIdx.x;
+  const int per = (B + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+  for (int i = threadIdx.x; i < d; i += 256) {
+    float sum = 0.f;
+    for (int b = b0; b < b1; ++b) {
+      const int r0 = cu[b];
+      if (l < cu[b + 1] - r0) sum += dx[((size_t)r0 + l) * d + i];
+    }
+    if (sum != 0.f) atomicAdd(dpos + (size_t)l * d + i, sum);
   }
 }
 
@@ -1069,14 +1113,22 @@ extern "C" int bd_layernorm_bwd_cast(const void* dy_bf16, const float* x, const 
   bd_drop_args da;
   BD_REQUIRE(bd_drop_make(drop, site, &da), "bd_layernorm_bwd: dropout p=%g outside [0, 1)", (double)drop->p);
   BD_REQUIRE(da.thr == 0u || (dx_bf16 != nullptr && d % 8 == 0), "bd_layernorm_bwd: dropout applies to the bf16 output (d %% 8 == 0)");
-  dim3 grid((M + 127) / 128), block(512);
+  // Rows per wave: about 320 workgroups of 8 waves, at most 16, an even number above 1. More workgroups mean more
+  // same-address atomics on the 2 d parameter-gradient sums (they retire one after another at the memory side:
+  // 10 k rows take 63 us at 1 row per wave, 30 us at 4 or 8), fewer mean idle CUs. A second stage that sums
+  // per-workgroup partial results needs a device-scope fence per workgroup, which on this part writes the
+  // workgroup's XCD L2 back and costs far more (150 us) than the atomics it saves.
+  int rpw = M / (8 * 320);
+  rpw = rpw < 1 ? 1 : (rpw > 16 ? 16 : rpw);
+  if (rpw > 1) rpw &= ~1;
+  dim3 grid((M + 8 * rpw - 1) / (8 * rpw)), block(512);
   const size_t lds = 2 * (size_t)d * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   const unsigned short* dy = (const unsigned short*)dy_bf16;
   unsigned short* ob = (unsigned short*)dx_bf16;
   const int nv = (d / 4 + 63) / 64;
   bd_prof_scope prof(stream, (double)M * d * (2.0 + 4.0 + 4.0 + 4.0 + (dx_bf16 ? 2.0 : 0.0)), BD_PROF_LN);
-#define BD_LNB(NV) hipLaunchKernelGGL(layernorm_bwd_kernel<NV>, grid, block, lds, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d, ob, da)
+#define BD_LNB(NV) hipLaunchKernelGGL(layernorm_bwd_kernel<NV>, grid, block, lds, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d, ob, da, rpw)
   if (nv <= 1) BD_LNB(1);
   else if (nv <= 2) BD_LNB(2);
   else if (nv <= 4) BD_LNB(4);
@@ -1184,9 +1236,9 @@ extern "C" int bd_attention_bwd(const void* qkv, const unsigned char* keymask, c
   return bd_attention_bwd_drop(qkv, keymask, out, dout, lse, delta, dqkv, B, L, H, head_dim, nullptr, 0u, stream);
 }
 
-extern "C" int bd_attention_bwd_drop(const void* qkv, const unsigned char* keymask, const void* out, const void* dout,
-                                     const float* lse, float* delta, void* dqkv, int B, int L, int H, int head_dim,
-                                     const bd_dropout* drop, unsigned site, void* stream) {
+static int attention_bwd_impl(const void* qkv, const unsigned char* keymask, const void* out, const void* dout,
+                              const float* lse, float* delta, void* dqkv, const int* cu, int B, int L, int H, int head_dim,
+                              const bd_dropout* drop, unsigned site, void* stream) {
   BD_REQUIRE(qkv && out && dout && lse && delta && dqkv, "bd_attention_bwd: null operand");
   BD_REQUIRE(B > 0 && L > 0 && H > 0 && B <= 65535 && H <= 65535, "bd_attention_bwd: bad shape");
   bd_drop_args da;
@@ -1202,11 +1254,11 @@ extern "C" int bd_attention_bwd_drop(const void* qkv, const unsigned char* keyma
   unsigned short* dq = (unsigned short*)dqkv;
 #define BD_LAUNCH_BWD(DH)                                                                                        \
   if (da.thr != 0u) {                                                                                            \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, true>), grid, block, 0, s, q, keymask, o, dO, lse, delta, dq, L, H, scale, da);  \
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, true>), grid, block, 0, s, q, keymask, dO, lse, delta, dq, L, H, scale, da);    \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, true>), grid, block, 0, s, q, keymask, o, dO, lse, delta, dq, L, H, scale, da, cu);  \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, true>), grid, block, 0, s, q, keymask, dO, lse, delta, dq, L, H, scale, da, cu);    \
   } else {                                                                                                       \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, false>), grid, block, 0, s, q, keymask, o, dO, lse, delta, dq, L, H, scale, da); \
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, false>), grid, block, 0, s, q, keymask, dO, lse, delta, dq, L, H, scale, da);   \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, false>), grid, block, 0, s, q, keymask, o, dO, lse, delta, dq, L, H, scale, da, cu); \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, false>), grid, block, 0, s, q, keymask, dO, lse, delta, dq, L, H, scale, da, cu);   \
   }
   switch (head_dim) {
     case 32: BD_LAUNCH_BWD(32); break;
@@ -1216,6 +1268,19 @@ extern "C" int bd_attention_bwd_drop(const void* qkv, const unsigned char* keyma
   }
 #undef BD_LAUNCH_BWD
   return bd_check_launch("bd_attention_bwd");
+}
+
+extern "C" int bd_attention_bwd_drop(const void* qkv, const unsigned char* keymask, const void* out, const void* dout,
+                                     const float* lse, float* delta, void* dqkv, int B, int L, int H, int head_dim,
+                                     const bd_dropout* drop, unsigned site, void* stream) {
+  return attention_bwd_impl(qkv, keymask, out, dout, lse, delta, dqkv, nullptr, B, L, H, head_dim, drop, site, stream);
+}
+
+extern "C" int bd_attention_bwd_varlen(const void* qkv, const unsigned char* keymask, const void* out, const void* dout,
+                                       const float* lse, float* delta, void* dqkv, const int* cu_seqlens, int B, int L,
+                                       int H, int head_dim, const bd_dropout* drop, unsigned site, void* stream) {
+  BD_REQUIRE(cu_seqlens != nullptr, "bd_attention_bwd_varlen: null cu_seqlens");
+  return attention_bwd_impl(qkv, keymask, out, dout, lse, delta, dqkv, cu_seqlens, B, L, H, head_dim, drop, site, stream);
 }
 
 // ---- attention backward for callers that cannot allocate (HIP graph capture, tight serving loops): the
@@ -1255,20 +1320,42 @@ extern "C" int bd_attention_bwd_static(const void* qkv, const unsigned char* key
   return bd_attention_bwd_drop(qkv, keymask, out, dout, lse, delta, dqkv, B, L, H, head_dim, nullptr, 0u, stream);
 }
 
+static int embed_bwd_impl(const float* dx, const long long* ids, const long long* timesteps, float* dtok, float* dpos,
+                          float* dtime, const int* cu, int B, int L, int d, int pad_id, int vocab, int max_pos,
+                          int n_timesteps, void* stream);
+
 extern "C" int bd_embed_bwd(const float* dx, const long long* ids, const long long* timesteps, float* dtok,
                             float* dpos, float* dtime, int B, int L, int d, int pad_id, int vocab, int max_pos,
                             int n_timesteps, void* stream) {
+  return embed_bwd_impl(dx, ids, timesteps, dtok, dpos, dtime, nullptr, B, L, d, pad_id, vocab, max_pos, n_timesteps, stream);
+}
+
+extern "C" int bd_embed_bwd_varlen(const float* dx, const long long* ids, const long long* timesteps, float* dtok,
+                                   float* dpos, float* dtime, const int* cu_seqlens, int B, int L, int d, int pad_id,
+                                   int vocab, int max_pos, int n_timesteps, void* stream) {
+  BD_REQUIRE(cu_seqlens != nullptr, "bd_embed_bwd_varlen: null cu_seqlens");
+  return embed_bwd_impl(dx, ids, timesteps, dtok, dpos, dtime, cu_seqlens, B, L, d, pad_id, vocab, max_pos, n_timesteps,
+                        stream);
+}
+
+static int embed_bwd_impl(const float* dx, const long long* ids, const long long* timesteps, float* dtok, float* dpos,
+                          float* dtime, const int* cu, int B, int L, int d, int pad_id, int vocab, int max_pos,
+                          int n_timesteps, void* stream) {
   BD_REQUIRE(dx && ids && timesteps && dtok && dpos && dtime, "bd_embed_bwd: null operand");
   BD_REQUIRE(vocab > 0 && n_timesteps > 0, "bd_embed_bwd: empty table");
   BD_REQUIRE(L <= max_pos, "bd_embed_bwd: sequence length %d exceeds max_position_embeddings %d", L, max_pos);
   BD_REQUIRE(B > 0 && L > 0 && L <= EB_MAXL && d > 0, "bd_embed_bwd: bad shape B=%d L=%d d=%d", B, L, d);
   bd_prof_scope prof(stream, 2.0 * (double)B * L * d * 4.0, BD_PROF_EMBED);
   hipLaunchKernelGGL(embed_bwd_seq_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, dx, ids, timesteps, dtok,
-                     dtime, L, d, pad_id, vocab, n_timesteps);
+                     dtime, L, d, pad_id, vocab, n_timesteps, cu);
   // enough workgroups to fill the chip: the batch is cut into slices when there are few positions
   const int slices = L >= 512 ? 1 : (512 + L - 1) / L;
-  hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3((unsigned)L, (unsigned)(slices < B ? slices : B)), dim3(256), 0,
-                     (hipStream_t)stream, dx, dpos, B, L, d);
+  if (cu)
+    hipLaunchKernelGGL(embed_bwd_pos_varlen_kernel, dim3((unsigned)L, (unsigned)(slices < B ? slices : B)), dim3(256), 0,
+                       (hipStream_t)stream, dx, dpos, cu, B, d);
+  else
+    hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3((unsigned)L, (unsigned)(slices < B ? slices : B)), dim3(256), 0,
+                       (hipStream_t)stream, dx, dpos, B, L, d);
   return bd_check_launch("bd_embed_bwd");
 }
 

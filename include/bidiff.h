@@ -359,6 +359,35 @@ int bd_attention_bwd_drop(const void* qkv, const unsigned char* keymask, const v
                           const float* lse, float* delta, void* dqkv, int B, int L, int H, int head_dim,
                           const bd_dropout* drop, unsigned site, void* stream);
 
+/* ---- packed rows: the training step without the trailing padding of each sequence.
+ * The reference pads every sequence of a batch to a common length (collate_fn / dynamic_collate_fn,
+ * src/data/dataset.py:200-240) and runs the denoiser on all B * L rows; rows behind a sequence's last attended
+ * position receive no attention as keys, carry no loss and get no gradient (src/model/diffusion.py:190-207), so the
+ * training step may leave them out. Packed layout: sequence b occupies rows cu_seqlens[b] .. cu_seqlens[b + 1] - 1
+ * (int32 [B + 1], cu_seqlens[0] = 0) of every token-major tensor; rows from cu_seqlens[B] up to the (padded) row
+ * count are fillers. Key masks, log-sum-exp / delta buffers and the dropout rows of the attention probabilities keep
+ * their [B, L] / [B, H, L] layout; the token-row dropout sites count rows in the packed order. */
+
+/* rowmap[r] = b * L + l for packed row r (the logical token it holds), -1 for filler rows. */
+int bd_build_rowmap(const int* cu_seqlens, int B, int L, int n_rows, int* rowmap, void* stream);
+/* bd_embed_drop on packed rows: x[r] = embedding sum of logical token rowmap[r] (ids [B, L], timesteps [B]); filler
+ * rows become zeros. (src/model/backbone.py:234-247) */
+int bd_embed_rows(const long long* ids, const long long* timesteps, const int* rowmap, const float* tok_emb,
+                  const float* pos_emb, const float* time_emb, float* x, int n_rows, int L, int d, int vocab,
+                  int max_pos, int n_timesteps, const bd_dropout* drop, unsigned site, void* stream);
+/* bd_attention_fwd_drop / bd_attention_bwd_drop on packed qkv / out / dout / dqkv rows; keymask [B, L], lse and delta
+ * [B, H, L] as in the padded form. (src/model/backbone.py:54-67 and its autograd) */
+int bd_attention_fwd_varlen(const void* qkv, const unsigned char* keymask, void* out, float* lse,
+                            const int* cu_seqlens, int B, int L, int H, int head_dim, const bd_dropout* drop,
+                            unsigned site, void* stream);
+int bd_attention_bwd_varlen(const void* qkv, const unsigned char* keymask, const void* out, const void* dout,
+                            const float* lse, float* delta, void* dqkv, const int* cu_seqlens, int B, int L, int H,
+                            int head_dim, const bd_dropout* drop, unsigned site, void* stream);
+/* bd_embed_bwd with dx in packed rows (ids [B, L] and timesteps [B] stay logical). */
+int bd_embed_bwd_varlen(const float* dx, const long long* ids, const long long* timesteps, float* dtok, float* dpos,
+                        float* dtime, const int* cu_seqlens, int B, int L, int d, int pad_id, int vocab, int max_pos,
+                        int n_timesteps, void* stream);
+
 /* Scatter-add of the embedding-sum gradient into the three tables (the pad row of the token table
  * receives nothing, as nn.Embedding(padding_idx) does). Table sizes as in bd_embed: L > max_pos is rejected,
  * rows whose index lies outside its table add nothing. (autograd of src/model/backbone.py:234-246). */

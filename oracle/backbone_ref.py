@@ -22,11 +22,23 @@ class DropoutStream:
     4 i + 1 = attention probabilities [(b H + h) L + query, key], 4 i + 2 = GELU output [B*L, F],
     4 i + 3 = fc2 output [B*L, d]."""
 
-    def __init__(self, p, seed, step=0):
+    def __init__(self, p, seed, step=0, rowmap=None):
+        """``rowmap`` (packed-row training path): int array, rowmap[r] = logical token row b * L + l that physical
+        row r holds (-1: filler). The token-row sites then count rows in the packed order: logical row
+        rowmap[r] takes the factors of stream row r; rows that are left out keep factor 1 (they influence nothing)."""
         self.p, self.seed, self.step = float(p), int(seed), int(step)
+        self.rowmap = None if rowmap is None else [int(v) for v in rowmap]
 
     def factors(self, site, rows, cols, like):
         from . import sampler_ref
+        if self.rowmap is not None and site % 4 != 1:
+            import numpy as np
+            phys = sampler_ref.dropout_mask(self.seed, self.step, site, self.p, len(self.rowmap), cols)
+            m = np.ones((rows, cols), dtype=np.float32)
+            rm = np.asarray(self.rowmap)
+            keep = rm >= 0
+            m[rm[keep]] = phys[keep]
+            return torch.from_numpy(m).to(device=like.device, dtype=like.dtype)
         m = sampler_ref.dropout_mask(self.seed, self.step, site, self.p, rows, cols)
         return torch.from_numpy(m).to(device=like.device, dtype=like.dtype)
 

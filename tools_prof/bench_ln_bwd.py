@@ -4,7 +4,7 @@ sys.path.insert(0, 'discrete-diffusion-model-for-inverse-polymer-design_amd'); s
 from bidiff import _lib
 if len(sys.argv) > 1: _lib.LIB_PATH = sys.argv[1]
 dev = torch.device('cuda:0'); lib = _lib.lib(); s = _lib.stream_handle(); P = _lib.ptr
-M, d = 32768, 384
+M, d = (int(sys.argv[2]) if len(sys.argv) > 2 else 32768), 384
 dy = torch.randn(M, d, device=dev).bfloat16(); x = torch.randn(M, d, device=dev)
 stats = torch.stack([x.mean(1), 1 / x.std(1)], 1).contiguous(); g = torch.ones(d, device=dev)
 dx = torch.randn(M, d, device=dev); dg = torch.zeros(d, device=dev); db = torch.zeros(d, device=dev)

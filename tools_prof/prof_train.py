@@ -1,6 +1,7 @@
-import sys, os, time, torch
+"""The SMILES_BPE training step of bench.py alone (for rocprofv3 --kernel-trace --stats)."""
+import sys, torch
 sys.path.insert(0, 'discrete-diffusion-model-for-inverse-polymer-design_amd'); sys.path.insert(0, '.')
 import bench
 dev = torch.device('cuda:0'); torch.cuda.set_device(0)
-r = bench.train_bench(dev, 0, 1, 20, 5)
-print(r)
+r = bench.train_bench(dev, 0, 1, 40, 5, 0, 16)
+print({k: r[k] for k in ("value", "ms_per_step", "rows_computed_per_step", "all_rows_variant")})

@@ -18,10 +18,17 @@ ids = rs.randint(5, V, size=(batch, L)).astype(np.int64)
 attn = (np.arange(L)[None] < lens[:, None]).astype(np.int64)
 ids[attn == 0] = 0
 ids_d, attn_d = torch.from_numpy(ids).to(dev), torch.from_numpy(attn).to(dev)
+lens_l = lens.tolist()
 def step():
-    out = model(ids_d, attn_d); out["loss"].backward(); opt.step(max_norm=1.0); opt.zero_grad()
+    out = model(ids_d, attn_d, lengths=lens_l); out["loss"].backward(); opt.step(max_norm=1.0); opt.zero_grad()
 for _ in range(5): step()
 torch.cuda.synchronize()
+import time
+t0 = time.perf_counter()
+for _ in range(30): step()
+t_host = time.perf_counter() - t0
+torch.cuda.synchronize()
+print(f"30 steps: host enqueue {t_host / 30 * 1e3:.2f} ms per step, wall {(time.perf_counter() - t0) / 30 * 1e3:.2f} ms per step")
 torch.autograd.set_multithreading_enabled(False)
 pr = cProfile.Profile()
 pr.enable()
