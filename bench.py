@@ -262,7 +262,8 @@ def train_bench(dev, rank, world, steps, warmup, cpu_steps, threads, batch=256, 
 
 
 def variant_bench(dev, variant, B, L, T, world, rank):
-    """One more sampling configuration on the small backbone: SELFIES (V = 43) or Group SELFIES (V = 233)."""
+    """One more sampling configuration on the small backbone: SELFIES (V = 43), Group SELFIES (V = 233) or
+    SMILES_BPE (V = 803, where the chosen rows' vocabulary logits are a visible part of a reverse step)."""
     from bidiff import _lib
     from bidiff.model.backbone import DiffusionBackbone
     from bidiff.model.diffusion import DiscreteMaskingDiffusion
@@ -270,6 +271,9 @@ def variant_bench(dev, variant, B, L, T, world, rank):
     if variant == "selfies":
         from bidiff.sampling.selfies_sampler import ConstrainedSampler
         tok = synthetic.selfies_tokenizer()
+    elif variant == "bpe":
+        from bidiff.sampling.sampler import ConstrainedSampler
+        tok = synthetic.bpe_tokenizer()
     else:
         from bidiff.sampling.group_selfies_sampler import ConstrainedSampler
         tok = synthetic.group_selfies_tokenizer()
@@ -282,6 +286,9 @@ def variant_bench(dev, variant, B, L, T, world, rank):
     lib = _lib.lib()
 
     def run(i):
+        if variant == "bpe":
+            ids, am, fm = smp.initial_state(B, L)
+            return smp._core.run(ids, am, fm, seq_offset=(i * world + rank) * B)
         ids = torch.full((B, L), tok.mask_token_id, dtype=torch.long, device=dev)
         ids[:, 0] = tok.bos_token_id
         ids[:, -1] = tok.eos_token_id
@@ -297,7 +304,8 @@ def variant_bench(dev, variant, B, L, T, world, rank):
     table = prof_table(lib, 1e3 * el)
     assert (out != tok.mask_token_id).all()
     fl = fwd_flops_per_token(384, 6, 1536, L, tok.vocab_size) * L * T * B
-    return {"metric": f"generated sequences/sec (Bi_Diffusion_{'SELFIES' if variant == 'selfies' else 'Group_SELFIES'} reverse sampling)",
+    rep = {"selfies": "SELFIES", "group": "Group_SELFIES", "bpe": "SMILES_BPE"}[variant]
+    return {"metric": f"generated sequences/sec (Bi_Diffusion_{rep} reverse sampling)",
             "value": B / el, "unit": "sequences/s (per GPU)", "ms_per_batch": 1e3 * el,
             "config": {"workload": f"small backbone, V={tok.vocab_size}, batch {B}, L={L}, T={T}, constraints on"},
             "whole_path_tflops": fl / el / 1e12, "roofline": roofline_of(table), "kernels": named(table)}
@@ -441,6 +449,7 @@ def main():
         configs = {}
         for name, fn in (("selfies", lambda: variant_bench(dev, "selfies", B, L, T, world, rank)),
                          ("group_selfies", lambda: variant_bench(dev, "group", B, L, T, world, rank)),
+                         ("smiles_bpe", lambda: variant_bench(dev, "bpe", B, L, 50, world, rank)),
                          ("c5_24L_d1024_L512", lambda: c5_bench(dev, args.c5_batch, 512, T))):
             torch.cuda.empty_cache()
             try:

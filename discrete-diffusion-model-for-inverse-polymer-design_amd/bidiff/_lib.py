@@ -81,6 +81,7 @@ class StepArgs(C.Structure):
         ("temperature", C.c_float),
         ("seed", C.c_ulonglong),
         ("seq_offset", C.c_longlong),
+        ("row_logits", VP), ("row_pos", VP), ("row_cap", C.c_int),
     ]
 
 

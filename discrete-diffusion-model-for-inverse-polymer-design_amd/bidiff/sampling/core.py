@@ -121,6 +121,10 @@ class ReverseSampler:
         self._ktab: Dict[int, torch.Tensor] = {}
         self.seed: Optional[int] = None      # fixed Philox seed (tests); None = draw from torch's generator
         self.record = None                   # list collecting per-step snapshots when not None
+        # Chosen-row workspace of the step kernel (raw logits of the rows a step draws, computed for the whole batch
+        # as one product ahead of the draws): None = when the vocabulary is large enough to pay (V > 128).
+        self.row_workspace: Optional[bool] = None
+        self.row_cap_max = 16
 
     def _tables(self):
         if self._dt is None:
@@ -181,6 +185,19 @@ class ReverseSampler:
         a.seed = seed
         a.seq_offset = int(seq_offset)
 
+        use_rows = self.row_workspace if self.row_workspace is not None else tt.V > 128
+        use_rows = bool(use_rows) and d in (128, 256, 384, 512)
+        if use_rows:
+            # A sequence that starts with n masks draws about n / T of them per step (k = max(1, int(n_t / t)) keeps
+            # n_t near n t / T), at most ceil(L / T): the workspace covers that many rows per sequence, rounded up to
+            # a power of two; the rare draws beyond it compute their row one by one.
+            row_cap = 1
+            while row_cap < min(self.row_cap_max, -(-L // self.num_steps)):
+                row_cap *= 2
+            vs = (tt.V + 31) // 32 * 32
+            row_logits = torch.empty(B * row_cap, vs, dtype=torch.float32, device=dev)
+            row_pos = torch.empty(B * row_cap, dtype=torch.int32, device=dev)
+
         steps = range(self.num_steps, 0, -1)
         if progress is not None:
             steps = progress(steps)
@@ -203,10 +220,13 @@ class ReverseSampler:
                 backbone.run_forward(ids, ts, keymask, want_hidden=False, want_logits=True, logits_out=logits)
                 raw = logits.clone() if self.record is not None else None
                 a.hidden, a.wout, a.logits = None, None, logits.data_ptr()
+                a.row_logits, a.row_pos, a.row_cap = None, None, 0
                 final_logits = logits
             else:
                 backbone.run_forward(ids, ts, keymask, want_hidden=True, want_logits=False, hidden_out=hidden)
                 a.hidden, a.wout = hidden.data_ptr(), pk.w_out.data_ptr()
+                if use_rows:
+                    a.row_logits, a.row_pos, a.row_cap = row_logits.data_ptr(), row_pos.data_ptr(), row_cap
                 if dump is not None:
                     dump.zero_()
                     a.logits = dump.data_ptr()

@@ -89,7 +89,7 @@ __global__ void attn_pack_kernel(const unsigned short* __restrict__ wqkv, const 
 template <int NT, int DH, int H = NT * 16 / DH>
 int launch_attn(const AttnArgs& a, hipStream_t stream) {
   const size_t lds = attn_phase_lds(NT, DH, H);
-  hipFuncSetAttribute((const void*)attn_block_kernel<NT, DH, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  BD_SET_MAX_LDS((attn_block_kernel<NT, DH, H>), lds);
   hipLaunchKernelGGL((attn_block_kernel<NT, DH, H>), dim3(a.B), dim3(256), lds, stream, a);
   return bd_check_launch("bd_attn_block_fused");
 }

@@ -139,7 +139,7 @@ template <int NT, int DH, int H = NT * 16 / DH>
 int launch_mega(const MegaArgs& a, hipStream_t stream) {
   const size_t la = attn_phase_lds(NT, DH, H), lf = ffn_phase_lds(NT, a.F);
   const size_t lds = la > lf ? la : lf;
-  hipFuncSetAttribute((const void*)backbone_mega_kernel<NT, DH, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  BD_SET_MAX_LDS((backbone_mega_kernel<NT, DH, H>), lds);
   hipLaunchKernelGGL((backbone_mega_kernel<NT, DH, H>), dim3(a.B), dim3(256), lds, stream, a);
   return bd_check_launch("bd_backbone_mega");
 }

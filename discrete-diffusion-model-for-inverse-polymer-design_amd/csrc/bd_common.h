@@ -26,6 +26,20 @@ int bd_check_launch(const char* what);
     if (!(cond)) return bd_fail(BD_ERR_ARG, __VA_ARGS__);      \
   } while (0)
 
+// Raise a kernel's dynamic-LDS limit to `bytes`: one runtime call per kernel instantiation, device and size
+// reached, not one per launch (the attribute is per device and only ever needs to grow).
+#define BD_SET_MAX_LDS(kernel, bytes)                                                                   \
+  do {                                                                                                  \
+    static int bd_lds_set_[64];                                                                         \
+    int bd_dev_ = 0;                                                                                    \
+    (void)hipGetDevice(&bd_dev_);                                                                       \
+    int* bd_slot_ = &bd_lds_set_[bd_dev_ & 63];                                                         \
+    if (__atomic_load_n(bd_slot_, __ATOMIC_ACQUIRE) < (int)(bytes)) {                                   \
+      (void)hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+      __atomic_store_n(bd_slot_, (int)(bytes), __ATOMIC_RELEASE);                                       \
+    }                                                                                                   \
+  } while (0)
+
 __device__ __forceinline__ float bd_bf16_to_f32(unsigned short b) {
   return __uint_as_float(((unsigned int)b) << 16);
 }

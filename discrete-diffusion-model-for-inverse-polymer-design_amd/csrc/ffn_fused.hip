@@ -110,7 +110,7 @@ extern "C" int bd_ffn_pack_weights(const void* w1, const void* w2, void* out, in
 template <int NT>
 static int launch_ffn(const FfnArgs& a, hipStream_t stream) {
   const size_t lds = ffn_phase_lds(NT, a.ph.F);
-  hipFuncSetAttribute((const void*)ffn_fused_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  BD_SET_MAX_LDS((ffn_fused_kernel<NT>), lds);
   hipLaunchKernelGGL((ffn_fused_kernel<NT>), dim3((a.M + 127) / 128), dim3(256), lds, stream, a);
   return bd_check_launch("bd_ffn_fused");
 }

@@ -491,7 +491,7 @@ int launch(const GemmArgs& a, hipStream_t s) {
   void* tok = bd_prof_on() ? bd_prof_begin(s) : nullptr;
   if (use_gemm256(a)) {
     const long long nt = (((long long)a.M + 255) / 256) * (a.Npad / 256);
-    hipFuncSetAttribute((const void*)gemm256_kernel<EPI, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G256_STAGE);
+    BD_SET_MAX_LDS((gemm256_kernel<EPI, DROP>), 2 * G256_STAGE);
     hipLaunchKernelGGL((gemm256_kernel<EPI, DROP>), dim3((unsigned)nt), dim3(256), 2 * G256_STAGE, s, a);
   } else {
     hipLaunchKernelGGL((gemm_bf16_kernel<EPI, DROP>), dim3(persistent_grid(a.n_tiles)), dim3(256), 0, s, a);

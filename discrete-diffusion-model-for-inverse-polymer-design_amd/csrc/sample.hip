@@ -100,7 +100,180 @@ __device__ __forceinline__ bool forbidden_at(const bd_step_args& p, const Smem& 
   return false;
 }
 
-__global__ __launch_bounds__(64) void sample_step_kernel(bd_step_args p) {
+// Start-of-step ids and position flags of sequence b into LDS.
+__device__ __forceinline__ void load_ids_and_flags(const bd_step_args& p, const Smem& s, int b, int lane) {
+  const int L = p.L;
+  const long long* ids_g = p.ids + (size_t)b * L;
+  for (int l = lane; l < L; l += 64) {
+    const int id = (int)ids_g[l];
+    s.ids[l] = id;
+    int f = (id == p.mask_id) ? PF_MASK0 : 0;
+    if ((p.variant & BD_VB_FIXED) && p.fixed && p.fixed[(size_t)b * L + l]) f |= PF_FIXED;
+    s.pf[l] = (unsigned char)f;
+  }
+  for (int r = lane; r < p.R; r += 64) { s.ringcnt[r] = 0; s.ringforbid[r] = 0; }
+  __syncthreads();
+}
+
+// The k = ktable[n_sel] selectable masked positions with the smallest keys, in draw order, into s.sel; returns k.
+// A function of the sequence's ids, fixed flags, seed and step alone (the chosen-row kernels repeat it).
+__device__ __forceinline__ int choose_positions(const bd_step_args& p, const Smem& s, int b, int lane, int n_sel) {
+  const int L = p.L;
+  const int CH = (L + 63) / 64;
+  const int l0 = lane * CH;
+  const uint32_t seq = (uint32_t)(p.seq_offset + b);
+  int k_sel = 0;
+  if (n_sel > 0) {
+    k_sel = p.ktable[n_sel];
+    k_sel = k_sel < 1 ? 1 : (k_sel > n_sel ? n_sel : k_sel);
+    for (int l = lane; l < L; l += 64) {
+      const int f = s.pf[l];
+      unsigned int kb = 0xffffffffu;
+      if ((f & PF_MASK0) && !(f & PF_FIXED)) {
+        const float u = p.u_sel ? p.u_sel[(size_t)b * L + l]
+                                : bd_uniform_select(p.seed, seq, (uint32_t)p.t, (uint32_t)l);
+        kb = __float_as_uint(u) & 0x7fffffffu;
+      }
+      s.key[l] = kb;
+    }
+    __syncthreads();
+    for (int round = 0; round < k_sel; ++round) {
+      unsigned long long best = ~0ull;
+      for (int j = 0; j < CH; ++j) {
+        const int l = l0 + j;
+        if (l < L) {
+          const unsigned int kb = s.key[l];
+          if (kb != 0xffffffffu) {
+            const unsigned long long ck = ((unsigned long long)kb << 32) | (unsigned int)l;
+            best = ck < best ? ck : best;
+          }
+        }
+      }
+      best = wave_min_u64(best);
+      const int pos = (int)(best & 0xffffffffu);
+      if (lane == 0) { s.sel[round] = (short)pos; s.key[pos] = 0xffffffffu; }
+      __syncthreads();
+    }
+    if (p.variant & BD_VB_SORTED) {
+      // ascending-position order: rank each chosen position among the chosen
+      for (int i = lane; i < k_sel; i += 64) s.key[i] = (unsigned int)s.sel[i];
+      __syncthreads();
+      for (int i = lane; i < k_sel; i += 64) {
+        const unsigned int mine = s.key[i];
+        int rank = 0;
+        for (int j = 0; j < k_sel; ++j) rank += (s.key[j] < mine);
+        s.sel[rank] = (short)mine;
+      }
+      __syncthreads();
+    }
+  }
+  return k_sel;
+}
+
+// ---- chosen-row logits ahead of the draws (HIDDEN mode with a row workspace) -----------------------------
+// Which positions a step draws is fixed before its first draw, and a row's raw logits do not depend on the
+// draws. So the first row_cap rows of every sequence are gathered into one (rows x V x d) product on the matrix
+// cores, where 32 rows share each pass over the output projection, instead of one wave re-reading the whole
+// projection for every row it draws (V * d * 2 bytes each: 617 KB at V = 803, d = 384).
+
+// row_pos[b * cap + i] = position of sequence b's i-th draw of this step, or -1.
+__global__ __launch_bounds__(64) void choose_rows_kernel(bd_step_args p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Smem s;
+  const int lane = threadIdx.x, b = blockIdx.x, L = p.L;
+  smem_carve(s, smem_raw, L, p.V, p.d, p.R > 0 ? p.R : 1);
+  load_ids_and_flags(p, s, b, lane);
+  int n_sel = 0;
+  for (int l = lane; l < L; l += 64) {
+    const int f = s.pf[l];
+    n_sel += (f & PF_MASK0) && !(f & PF_FIXED);
+  }
+  n_sel = bd_wave_sum_i(n_sel);
+  const int k_sel = choose_positions(p, s, b, lane, n_sel);
+  for (int i = lane; i < p.row_cap; i += 64) p.row_pos[(size_t)b * p.row_cap + i] = i < k_sel ? (int)s.sel[i] : -1;
+}
+
+// row_logits[slot][v] = hidden[b, row_pos[slot], :] . wout[v, :] for the occupied slots. A workgroup = 4 waves =
+// 4 x 32 slots over a quarter of the vocabulary (blockIdx.y); every wave keeps its 32 hidden rows as MFMA operands
+// in registers for the whole pass. The projection rows of a vocabulary tile (32 x d bf16, contiguous in memory)
+// are fetched once per workgroup with full-line loads into a double-buffered LDS tile and read from there as
+// operands by the four waves: fetched straight from memory in operand order, every load instruction touches 32
+// lines for 32 bytes each and the CU's line rate, not the matrix cores, sets the pace (3 x slower).
+template <int NK>   // d / 16
+__global__ __launch_bounds__(256) void row_logits_kernel(bd_step_args p, int VS) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wtile[];
+  constexpr int ROWB = NK * 32 + 16;         // bytes per projection row in LDS (+16: rows r and r + 1 start 4 banks apart)
+  constexpr int TILEB = 32 * ROWB;
+  constexpr int CHUNKS = 64 * NK;            // 16-byte pieces per tile
+  constexpr int PER = (CHUNKS + 255) / 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, kh = lane >> 5;
+  const int d = p.d, V = p.V;
+  const long long n_slots = (long long)p.B * p.row_cap;
+  const long long slot = ((long long)blockIdx.x * 4 + wave) * 32 + r;
+  int pos = -1;
+  long long b = 0;
+  if (slot < n_slots) { pos = p.row_pos[slot]; b = slot / p.row_cap; }
+  if (!__syncthreads_or(pos >= 0)) return;
+  const bool active = __ballot(pos >= 0) != 0ull;
+  const unsigned short* hrow = (const unsigned short*)p.hidden + ((size_t)b * p.L + (pos >= 0 ? pos : 0)) * d + 8 * kh;
+  bf16x8 hf[NK];
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) hf[ks] = *(const bf16x8*)(hrow + 16 * ks);
+  const int n_tiles = (V + 31) / 32;
+  const int t0 = n_tiles * blockIdx.y / gridDim.y, t1 = n_tiles * (blockIdx.y + 1) / gridDim.y;
+  const unsigned char* wout = (const unsigned char*)p.wout;
+  float* out = p.row_logits + (size_t)slot * VS;
+  u32x4 stage[PER];
+  auto fetch = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c = tid + 256 * i;
+      if (CHUNKS % 256 == 0 || c < CHUNKS) {
+        const int row = c / (2 * NK), cc = c - row * (2 * NK);
+        stage[i] = *(const u32x4*)(wout + ((size_t)min(32 * t + row, V - 1) * d) * 2 + cc * 16);
+      }
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c = tid + 256 * i;
+      if (CHUNKS % 256 == 0 || c < CHUNKS) {
+        const int row = c / (2 * NK), cc = c - row * (2 * NK);
+        *(u32x4*)(wtile + buf * TILEB + row * ROWB + cc * 16) = stage[i];
+      }
+    }
+  };
+  if (t0 < t1) fetch(t0);
+  for (int t = t0; t < t1; ++t) {
+    const int buf = (t - t0) & 1;
+    stash(buf);
+    __syncthreads();
+    if (t + 1 < t1) fetch(t + 1);
+    if (!active) continue;
+    const unsigned char* wfrag = wtile + buf * TILEB + r * ROWB + kh * 16;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < NK; ks += 2) {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(wfrag + 32 * ks), hf[ks], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(wfrag + 32 * ks + 32), hf[ks + 1], acc1, 0, 0, 0);
+    }
+    // lane: slot r, vocabulary entries 32 t + 8 g + 4 kh + (0..3)
+    if (pos >= 0) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 o = {acc0[4 * g] + acc1[4 * g], acc0[4 * g + 1] + acc1[4 * g + 1], acc0[4 * g + 2] + acc1[4 * g + 2],
+                   acc0[4 * g + 3] + acc1[4 * g + 3]};
+        *(f32x4*)(out + 32 * t + 8 * g + 4 * kh) = o;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void sample_step_kernel(bd_step_args p, int VS) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem s;
   const int lane = threadIdx.x;
@@ -118,16 +291,7 @@ __global__ __launch_bounds__(64) void sample_step_kernel(bd_step_args p) {
   const unsigned short* hidden = (const unsigned short*)p.hidden;
   const unsigned short* wout = (const unsigned short*)p.wout;
 
-  // ---- load ids, start-of-step flags
-  for (int l = lane; l < L; l += 64) {
-    const int id = (int)ids_g[l];
-    s.ids[l] = id;
-    int f = (id == p.mask_id) ? PF_MASK0 : 0;
-    if ((p.variant & BD_VB_FIXED) && p.fixed && p.fixed[(size_t)b * L + l]) f |= PF_FIXED;
-    s.pf[l] = (unsigned char)f;
-  }
-  for (int r = lane; r < p.R; r += 64) { s.ringcnt[r] = 0; s.ringforbid[r] = 0; }
-  __syncthreads();
+  load_ids_and_flags(p, s, b, lane);
 
   // ---- per-sequence counts: masked, selectable, counted-token total
   int n_mask = 0, n_sel = 0, total = 0;
@@ -311,59 +475,20 @@ __global__ __launch_bounds__(64) void sample_step_kernel(bd_step_args p) {
     }
   }
 
-  // ---- choose the k smallest keys among the selectable masked positions
-  int k_sel = 0;
-  if (n_sel > 0) {
-    k_sel = p.ktable[n_sel];
-    k_sel = k_sel < 1 ? 1 : (k_sel > n_sel ? n_sel : k_sel);
-    for (int l = lane; l < L; l += 64) {
-      const int f = s.pf[l];
-      unsigned int kb = 0xffffffffu;
-      if ((f & PF_MASK0) && !(f & PF_FIXED)) {
-        const float u = p.u_sel ? p.u_sel[(size_t)b * L + l]
-                                : bd_uniform_select(p.seed, seq, (uint32_t)p.t, (uint32_t)l);
-        kb = __float_as_uint(u) & 0x7fffffffu;
-      }
-      s.key[l] = kb;
-    }
-    __syncthreads();
-    for (int round = 0; round < k_sel; ++round) {
-      unsigned long long best = ~0ull;
-      for (int j = 0; j < CH; ++j) {
-        const int l = l0 + j;
-        if (l < L) {
-          const unsigned int kb = s.key[l];
-          if (kb != 0xffffffffu) {
-            const unsigned long long ck = ((unsigned long long)kb << 32) | (unsigned int)l;
-            best = ck < best ? ck : best;
-          }
-        }
-      }
-      best = wave_min_u64(best);
-      const int pos = (int)(best & 0xffffffffu);
-      if (lane == 0) { s.sel[round] = (short)pos; s.key[pos] = 0xffffffffu; }
-      __syncthreads();
-    }
-    if (p.variant & BD_VB_SORTED) {
-      // ascending-position order: rank each chosen position among the chosen
-      for (int i = lane; i < k_sel; i += 64) s.key[i] = (unsigned int)s.sel[i];
-      __syncthreads();
-      for (int i = lane; i < k_sel; i += 64) {
-        const unsigned int mine = s.key[i];
-        int rank = 0;
-        for (int j = 0; j < k_sel; ++j) rank += (s.key[j] < mine);
-        s.sel[rank] = (short)mine;
-      }
-      __syncthreads();
-    }
-  }
+  const int k_sel = choose_positions(p, s, b, lane, n_sel);
 
   // ---- sequential draws
   for (int it = 0; it < k_sel; ++it) {
     const int pos = s.sel[it];
     if (s.ids[pos] != p.mask_id) continue;  // filled by an EOS termination earlier in this step
     const int pflag = s.pf[pos];
-    if (!logits_mode) {
+    const bool have_row = !logits_mode && p.row_logits != nullptr && it < p.row_cap;
+    if (have_row) {
+      const float* rl = p.row_logits + ((size_t)b * p.row_cap + it) * VS;
+      for (int v = lane; v < V; v += 64) s.row[v] = rl[v];
+      __syncthreads();
+    }
+    if (!logits_mode && !have_row) {
       const unsigned short* hr = hidden + ((size_t)b * L + pos) * d;
       for (int k = lane * 8; k < d; k += 512) {
         const u32x4 w = *(const u32x4*)(hr + k);
@@ -375,7 +500,7 @@ __global__ __launch_bounds__(64) void sample_step_kernel(bd_step_args p) {
       }
       __syncthreads();
     }
-    if (!logits_mode) {
+    if (!logits_mode && !have_row) {
       // logits of this row: the wave walks the vocabulary, every lane multiplies its 8-feature slices of
       // the weight row with the hidden row (coalesced 16-byte loads, independent across v), a wave sum
       // completes the dot product and lane v % 64 keeps it in s.row[v]
@@ -714,7 +839,30 @@ extern "C" int bd_sample_step(const bd_step_args* a, void* stream) {
   BD_REQUIRE(lds <= 64 * 1024, "bd_sample_step: working set of %zu bytes per sequence exceeds LDS", lds);
   // ids in and out, fixed mask, and (hidden mode) about one hidden row and its result per chosen position
   bd_prof_scope prof(stream, (double)p.B * (17.0 * p.L + (p.hidden ? 2.0 * p.d + 8.0 : 4.0 * p.L * p.V)), BD_PROF_SAMPLE);
-  hipLaunchKernelGGL(sample_step_kernel, dim3(p.B), dim3(64), lds, (hipStream_t)stream, p);
+  const int VS = (p.V + 31) & ~31;   // row stride of the chosen-row workspace
+  if (p.hidden != nullptr && p.row_logits != nullptr) {
+    BD_REQUIRE(p.row_pos != nullptr, "bd_sample_step: row workspace without row_pos");
+    BD_REQUIRE(p.row_cap >= 1 && p.row_cap <= 32 && (p.row_cap & (p.row_cap - 1)) == 0,
+               "bd_sample_step: row_cap=%d is not a power of two in 1..32", p.row_cap);
+    BD_REQUIRE(p.d % 16 == 0 && p.d <= 512 && (p.d / 16) % 8 == 0,
+               "bd_sample_step: the chosen-row workspace needs d in {128, 256, 384, 512}, not %d", p.d);
+    hipLaunchKernelGGL(choose_rows_kernel, dim3(p.B), dim3(64), lds, (hipStream_t)stream, p);
+    const dim3 grid((unsigned)(((long long)p.B * p.row_cap + 127) / 128), 4);
+#define BD_ROWS(NK)                                                                            \
+  do {                                                                                         \
+    const int wl = 2 * 32 * (NK * 32 + 16);                                                    \
+    BD_SET_MAX_LDS((row_logits_kernel<NK>), wl);                                               \
+    hipLaunchKernelGGL(row_logits_kernel<NK>, grid, dim3(256), wl, (hipStream_t)stream, p, VS); \
+  } while (0)
+    switch (p.d / 16) {
+      case 8: BD_ROWS(8); break;
+      case 16: BD_ROWS(16); break;
+      case 24: BD_ROWS(24); break;
+      default: BD_ROWS(32); break;
+    }
+#undef BD_ROWS
+  }
+  hipLaunchKernelGGL(sample_step_kernel, dim3(p.B), dim3(64), lds, (hipStream_t)stream, p, VS);
   return bd_check_launch("bd_sample_step");
 }
 

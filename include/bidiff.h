@@ -498,6 +498,14 @@ typedef struct bd_step_args {
   float temperature;
   unsigned long long seed;
   long long seq_offset;
+  /* HIDDEN mode, optional workspace: the raw logits of each sequence's first row_cap draws of the step are
+   * computed ahead of the draws as one product on the matrix cores (32 rows share each pass over wout); draws
+   * beyond row_cap compute their row one by one as without the workspace. row_cap a power of two <= 32,
+   * d in {128, 256, 384, 512}. Which path a draw takes depends on its rank in its own sequence only, so a
+   * sequence's result does not depend on the batch it is in.                                               */
+  float* row_logits;            /* [B * row_cap, (V + 31) / 32 * 32] or null                           */
+  int* row_pos;                 /* [B * row_cap]                                                        */
+  int row_cap;
 } bd_step_args;
 
 /* One reverse step t for a batch: static constraints, choice of k positions per sequence,

@@ -121,8 +121,9 @@ def hip_tables(tb, device):
 
 def hip_step(tb, dt, ids, ktable_row, t, logits=None, hidden=None, wout=None, dump=None, temperature=1.0,
              use_constraints=True, fixed=None, u_sel=None, u_tok=None, seed=0, seq_offset=0, natural_eos=False,
-             attn=None, keymask=None, has_eos=None, variant_extra=0):
-    """Call bd_sample_step on device tensors (mutated in place)."""
+             attn=None, keymask=None, has_eos=None, variant_extra=0, row_cap=0):
+    """Call bd_sample_step on device tensors (mutated in place). ``row_cap`` > 0 (hidden mode): with the chosen-row
+    workspace, the first ``row_cap`` rows of each sequence computed ahead of the draws."""
     import ctypes as C
     import torch
     from bidiff import _lib
@@ -153,6 +154,10 @@ def hip_step(tb, dt, ids, ktable_row, t, logits=None, hidden=None, wout=None, du
     a.use_constraints, a.t = int(use_constraints), int(t)
     a.temperature = float(temperature)
     a.seed, a.seq_offset = int(seed), int(seq_offset)
+    if row_cap:
+        rl = torch.full((B * row_cap, (tb.V + 31) // 32 * 32), float("nan"), device=ids.device)
+        rp = torch.full((B * row_cap,), -7, dtype=torch.int32, device=ids.device)
+        a.row_logits, a.row_pos, a.row_cap = rl.data_ptr(), rp.data_ptr(), int(row_cap)
     _lib.check(_lib.lib().bd_sample_step(C.byref(a), _lib.stream_handle()), "bd_sample_step")
     torch.cuda.synchronize()
 

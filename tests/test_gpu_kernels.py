@@ -338,7 +338,7 @@ def test_ffn_fused_unsupported_shapes_are_refused(gpu_device):
 
 
 # ---------------------------------------------------------------- fused attention block
-def _attn_block_case(gpu_device, B, L, d, H, masked, seed):
+def _attn_block_case(gpu_device, B, L, d, H, masked, seed, keep=None, in_place=False):
     g = torch.Generator().manual_seed(seed)
     dh = d // H
     x = torch.randn(B * L, d, generator=g) * 1.5 + 0.3
@@ -354,6 +354,10 @@ def _attn_block_case(gpu_device, B, L, d, H, masked, seed):
         for b in range(B):
             km[b, int(torch.randint(1, L + 1, (1,), generator=g)):] = 0
         km[B - 1] = 0                                       # a fully masked sequence
+    if keep is not None:                                    # the same draw, only these sequences submitted
+        x = x.view(B, L, d)[keep].reshape(-1, d).contiguous()
+        km = km[keep].contiguous() if km is not None else None
+        B = len(keep)
     lib = _lib.lib()
     scale = math.log2(math.e) / math.sqrt(dh)
     wf = Wqkv * gm[None, :]
@@ -374,7 +378,7 @@ def _attn_block_case(gpu_device, B, L, d, H, masked, seed):
     pack = torch.empty(lib.bd_attn_pack_bytes_heads(d, H), dtype=torch.uint8, device=gpu_device)
     _lib.check(lib.bd_attn_pack_weights(_lib.ptr(wqkv_b), _lib.ptr(wo_b), _lib.ptr(pack), d, H, _s()), "attn pack")
     xd = x.to(gpu_device)
-    out = torch.empty_like(xd)
+    out = xd if in_place else torch.empty_like(xd)
     bfd = bf[:aw].contiguous().to(gpu_device)
     bod = bo.to(gpu_device)
     bofd = (bo + Wo_p @ bf[2 * aw:]).to(gpu_device)
@@ -417,6 +421,13 @@ def test_attn_block_fused_sequences_independent_and_in_place(gpu_device):
     out, _, xs, _ = _attn_block_case(gpu_device, B, L, d, H, True, seed=11)
     out2, _, _, _ = _attn_block_case(gpu_device, B, L, d, H, True, seed=11)
     assert torch.equal(out, out2)                            # deterministic
+    # a sequence's rows depend on no other sequence of the launch: any subset, in any order, gives the same bits
+    keep = [4, 1, 5]
+    sub, _, _, _ = _attn_block_case(gpu_device, B, L, d, H, True, seed=11, keep=keep)
+    assert torch.equal(sub, out[keep])
+    # output written over the input
+    inp, _, _, _ = _attn_block_case(gpu_device, B, L, d, H, True, seed=11, in_place=True)
+    assert torch.equal(inp, out)
 
 
 @pytest.mark.gpu

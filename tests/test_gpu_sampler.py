@@ -114,11 +114,14 @@ def test_hip_step_philox_matches_oracle(gpu_device, variant, B, L, t, T):
         np.testing.assert_array_equal(d_ids.cpu().numpy(), of["ids"])
 
 
-@pytest.mark.parametrize("variant,L,d", [("smiles", 128, 384), ("selfies", 40, 128), ("group", 128, 256), ("bpe", 64, 384)])
-def test_hip_hidden_mode_matches_oracle_on_dumped_logits(gpu_device, variant, L, d):
+@pytest.mark.parametrize("row_cap", [0, 1, 4, 32])
+@pytest.mark.parametrize("variant,L,d", [("smiles", 128, 384), ("selfies", 40, 128), ("group", 128, 256), ("bpe", 64, 384),
+                                         ("bpe", 128, 512)])
+def test_hip_hidden_mode_matches_oracle_on_dumped_logits(gpu_device, variant, L, d, row_cap):
     """HIDDEN mode (vocabulary logits computed in-kernel for the chosen rows only): the raw rows it
     used are dumped and replayed through the oracle, which must draw the same tokens; the dumped
-    rows themselves must equal hidden @ W_out^T."""
+    rows themselves must equal hidden @ W_out^T. ``row_cap`` > 0: the first row_cap rows of each sequence come
+    from the product computed ahead of the draws, the rest (t = 2 draws 5 rows per sequence) one by one."""
     dev = gpu_device
     B, T = 48, 100
     smp, tok = H.make_sampler(variant, num_steps=T)
@@ -135,7 +138,7 @@ def test_hip_hidden_mode_matches_oracle_on_dumped_logits(gpu_device, variant, L,
         has_eos = np.ones(B, dtype=np.uint8) if variant == "selfies" else None
         H.hip_step(tb, dt, d_ids, ktab[t], t, hidden=hidden, wout=wout, dump=dump, temperature=1.1,
                    fixed=None if fixed is None else torch.from_numpy(fixed).to(dev), seed=99, seq_offset=5,
-                   has_eos=None if has_eos is None else torch.from_numpy(has_eos).to(dev))
+                   has_eos=None if has_eos is None else torch.from_numpy(has_eos).to(dev), row_cap=row_cap)
         raw = dump.cpu().numpy()
         o = ora.sample_step(tb, ids, raw, ktab[t], t, temperature=1.1, fixed=fixed, seed=99, seq_offset=5,
                             has_eos=has_eos)
@@ -146,6 +149,41 @@ def test_hip_hidden_mode_matches_oracle_on_dumped_logits(gpu_device, variant, L,
         assert np.abs(raw[used] - full[used]).max() < 1e-3 * np.abs(full).max()
         changed = (d_ids.cpu().numpy() != ids)
         assert used.any(axis=-1)[changed].all(), "every drawn position must have a dumped row"
+
+
+@pytest.mark.parametrize("variant,L,d", [("bpe", 128, 384), ("selfies", 64, 256)])
+def test_hidden_mode_row_workspace_is_batch_independent(gpu_device, variant, L, d):
+    """A sequence's drawn tokens and the rows it used are the same bits whatever batch it is submitted in (which
+    path computes a row depends on the row's rank inside its own sequence only)."""
+    dev = gpu_device
+    B, T, t = 40, 100, 3
+    smp, tok = H.make_sampler(variant, num_steps=T)
+    tb = H.oracle_tables(smp)
+    dt = H.hip_tables(tb, dev)
+    rs = np.random.RandomState(7)
+    ktab = core.unmask_count_table(T, L)
+    ids, fixed = _random_state(rs, tb, B, L, 0.2, variant)       # about 8 draws per sequence at t = 3
+    hidden = torch.from_numpy(rs.standard_normal((B, L, d)).astype(np.float32)).to(dev).bfloat16()
+    wout = torch.from_numpy((rs.standard_normal((tb.V, d)) / np.sqrt(d) * 3).astype(np.float32)).to(dev).bfloat16()
+    has_eos = np.ones(B, dtype=np.uint8) if variant == "selfies" else None
+
+    def run(lo, hi, cap):
+        dump = torch.zeros(hi - lo, L, tb.V, device=dev)
+        d_ids = torch.from_numpy(ids[lo:hi].copy()).to(dev)
+        H.hip_step(tb, dt, d_ids, ktab[t], t, hidden=hidden[lo:hi].contiguous(), wout=wout, dump=dump,
+                   fixed=None if fixed is None else torch.from_numpy(fixed[lo:hi].copy()).to(dev), seed=5, seq_offset=100 + lo,
+                   has_eos=None if has_eos is None else torch.from_numpy(has_eos[lo:hi].copy()).to(dev), row_cap=cap)
+        return d_ids.cpu(), dump.cpu()
+
+    whole_ids, whole_dump = run(0, B, 4)
+    for lo, hi in ((0, 1), (13, 30), (37, 40)):
+        part_ids, part_dump = run(lo, hi, 4)
+        assert torch.equal(part_ids, whole_ids[lo:hi])
+        assert torch.equal(part_dump, whole_dump[lo:hi])
+    # without the workspace the rows are summed in another order: same tokens are not guaranteed, close rows are
+    _, plain_dump = run(0, B, 0)
+    used = (whole_dump != 0) & (plain_dump != 0)
+    assert (whole_dump[used] - plain_dump[used]).abs().max() < 1e-3 * plain_dump.abs().max()
 
 
 def test_step_rejects_bad_arguments(gpu_device):
