@@ -125,6 +125,7 @@ SIGNATURES = {
     "bd_masked_ce_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, VP]),
     "bd_layernorm_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, VP]),
     "bd_layernorm_bwd_cast": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, VP, VP, C.c_uint, VP]),
+    "bd_decode_ids": (C.c_int, [VP, C.c_int, C.c_int, VP, VP, C.c_int, VP, VP, C.c_int, VP]),
     "bd_gemm_wgrad_bf16": (C.c_int, [VP, C.c_int, VP, C.c_int, VP, C.c_int, C.c_int, C.c_int, VP]),
     "bd_gemm_wgrad_segments": (C.c_int, [VP, C.c_int, VP, C.c_int, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "bd_gemm_bf16_batched": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong, C.c_int, C.c_int,

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from . import core
+from .decode import decode_batch
 from .sampler import _progress
 
 
@@ -96,7 +97,7 @@ class ConstrainedSampler:
         self._core.use_constraints = bool(self.use_constraints)
         ids = self._core.run(ids, torch.ones_like(ids), None, seq_offset=seq_offset,
                              progress=_progress(show_progress, "Sampling"))
-        strings = self.tokenizer.batch_decode(ids.cpu().tolist(), skip_special_tokens=True)
+        strings = decode_batch(self, ids)
         return ids, strings
 
     def sample_batch(self, num_samples: int, seq_length: int, batch_size: int = 256,
@@ -201,7 +202,7 @@ class ConstrainedSampler:
         extra = core.VB_FIXED | core.VB_DYN_ALL_MASKS | core.VB_DYN_SINGLE
         ids = self._core.run(ids, torch.ones_like(ids), fixed, seq_offset=seq_offset,
                              progress=_progress(show_progress, "Sampling"), variant_extra=extra)
-        strings = self.tokenizer.batch_decode(ids.cpu().tolist(), skip_special_tokens=True)
+        strings = decode_batch(self, ids)
         return ids, strings
 
     # aliases the reference keeps for older callers (Group sampler.py:697-718) have no device

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from . import core
+from .decode import decode_batch
 
 
 def _progress(show, desc):
@@ -90,7 +91,7 @@ class ConstrainedSampler:
         self._core.use_constraints = bool(self.use_constraints)
         ids = self._core.run(ids, attention_mask, fixed_mask, seq_offset=seq_offset,
                              progress=_progress(show_progress, "Sampling"))
-        smiles = self.tokenizer.batch_decode(ids.cpu().tolist(), skip_special_tokens=True)
+        smiles = decode_batch(self, ids)
         return ids, smiles
 
     # ------------------------------------------------------------------ initial states

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from . import core
+from .decode import decode_batch
 from .sampler import _progress
 
 
@@ -72,7 +73,7 @@ class ConstrainedSampler:
         self._core.use_constraints = bool(self.use_constraints)
         ids = self._core.run(ids, attention_mask, None, natural_eos=allow_natural_eos, seq_offset=seq_offset,
                              progress=_progress(show_progress, "Sampling"), has_eos=has_eos)
-        strings = self.tokenizer.batch_decode(ids.cpu().tolist(), skip_special_tokens=True)
+        strings = decode_batch(self, ids)
         return ids, strings
 
     def sample_batch(self, num_samples: int, seq_length: int, batch_size: int = 256,
@@ -152,5 +153,5 @@ class ConstrainedSampler:
         extra = core.VB_FIXED | core.VB_DYN_ALL_MASKS | core.VB_SPECIAL_UNFIXED
         ids = self._core.run(ids, torch.ones_like(ids), fixed, natural_eos=natural, seq_offset=seq_offset,
                              progress=_progress(show_progress, "Sampling"), has_eos=has_eos, variant_extra=extra)
-        strings = self.tokenizer.batch_decode(ids.cpu().tolist(), skip_special_tokens=True)
+        strings = decode_batch(self, ids)
         return ids, strings

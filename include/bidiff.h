@@ -539,6 +539,15 @@ typedef struct bd_fix_args {
  * Bi_Diffusion_Group_SELFIES/src/sampling/sampler.py:247-315. */
 int bd_sample_fixup(const bd_fix_args* args, void* stream);
 
+/* Token ids -> text: out[b, :] = the texts of row b's tokens joined in position order, out_len[b] = its length
+ * in bytes (a value above `stride` means the row did not fit and was cut). text / offsets [V + 1]: the tokens'
+ * UTF-8 texts back to back; a token that decode skips (the special tokens) has an empty text, ids outside 0..V-1
+ * decode to nothing ('[UNK]' is a special token).
+ * replaces tokenizer.batch_decode(ids.cpu().tolist(), skip_special_tokens=True), src/sampling/sampler.py:724 with
+ * src/data/tokenizer.py:207-224,110-121 (same loop in the SMILES_BPE and SELFIES tokenizers). */
+int bd_decode_ids(const long long* ids, int B, int L, const unsigned char* text, const int* offsets, int V,
+                  unsigned char* out, int* out_len, int stride, void* stream);
+
 /* Host-side evaluation of the device uniform / Gumbel functions (testing aid; the product
  * never needs it): out[i] = gumbel(u[i]); Philox words for a counter/key. */
 void bd_host_gumbel(const float* u, float* out, long long n);
