@@ -146,6 +146,11 @@ SIGNATURES = {
     "bd_embed_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP] + [C.c_int] * 7 + [VP]),
     "bd_sumsq_f32": (C.c_int, [VP, C.c_longlong, VP, VP]),
     "bd_adamw_step": (C.c_int, [VP, VP, VP, VP, C.c_longlong] + [C.c_float] * 7 + [VP, C.c_float, VP]),
+    "bd_adamw_step_guarded": (C.c_int, [VP, VP, VP, VP, C.c_longlong, C.c_float, C.c_double, C.c_double, C.c_float, C.c_float,
+                                        VP, VP, C.c_float, VP]),
+    "bd_step_guard_update": (C.c_int, [VP, VP, VP]),
+    "bd_muon_step_guarded": (C.c_int, [VP, VP, VP, VP, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                       C.c_int, C.c_int, VP, C.c_float, VP]),
     "bd_multi_cast_bf16": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP]),
     "bd_cast_f32_to_bf16": (C.c_int, [VP, VP, C.c_longlong, VP]),
     "bd_gemm_panel_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),

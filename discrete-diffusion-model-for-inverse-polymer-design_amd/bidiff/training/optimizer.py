@@ -7,6 +7,12 @@ Replaces, for the default AdamW branch, ``build_step1_backbone_optimizer``
 (trainer_backbone.py:441-455). It is a ``torch.optim.Optimizer`` so the reference's LR
 schedulers and ``state_dict`` format (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``)
 keep working; the per-parameter tensors are views into the flat buffers.
+
+``skip_nonfinite`` (set by the trainer when AMP is on) gives ``step`` the behaviour of
+``GradScaler.unscale_`` + ``clip_grad_norm_`` + ``GradScaler.step`` (trainer_backbone.py:441-453): a step whose
+gradients hold an inf or NaN changes nothing and does not count for the bias corrections. The decision stays on
+the device (the reference's ``scaler.step`` synchronises the host every step to read ``found_inf``); the counts of
+applied and skipped steps come back only when ``state_dict`` / ``skipped_steps`` ask for them.
 """
 import math
 
@@ -32,6 +38,8 @@ class FlatAdamW(torch.optim.Optimizer):
         self.flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._step = 0
+        self.skip_nonfinite = False
+        self._guard = torch.zeros(2, dtype=torch.int32, device=dev)     # applied, skipped (skip_nonfinite steps)
         off = 0
         with torch.no_grad():
             for p in params:
@@ -89,6 +97,8 @@ class FlatAdamW(torch.optim.Optimizer):
         g = self.param_groups[0]
         self._step += 1
         b1, b2 = g["betas"]
+        if self.skip_nonfinite:
+            return self._guarded_step(g, b1, b2, max_norm)
         bc1 = 1.0 - b1 ** self._step
         bc2_sqrt = math.sqrt(1.0 - b2 ** self._step)
         ss = None
@@ -108,6 +118,36 @@ class FlatAdamW(torch.optim.Optimizer):
         _lib.bump_weights_generation()   # parameters changed behind torch's back: refresh bf16 copies
         return None
 
+    def _guarded_step(self, g, b1, b2, max_norm):
+        lib, s = _lib.lib(), _lib.stream_handle()
+        self._sumsq.zero_()
+        _lib.check(lib.bd_sumsq_f32(_lib.ptr(self.flat_grad), self.numel, _lib.ptr(self._sumsq), s), "bd_sumsq_f32")
+        _lib.check(lib.bd_adamw_step_guarded(_lib.ptr(self.flat_param), _lib.ptr(self.flat_grad), _lib.ptr(self.flat_m),
+                                             _lib.ptr(self.flat_v), self.numel, float(g["lr"]), float(b1), float(b2),
+                                             float(g["eps"]), float(g["weight_decay"]), _lib.ptr(self._guard),
+                                             _lib.ptr(self._sumsq), float(max_norm or 0.0), s), "bd_adamw_step_guarded")
+        _lib.check(lib.bd_step_guard_update(_lib.ptr(self._guard), _lib.ptr(self._sumsq), s), "bd_step_guard_update")
+        self._steps_stale = True
+        _lib.bump_weights_generation()
+        return None
+
+    def _refresh_steps(self):
+        """Per-parameter ``step`` entries from the device's count of applied steps (one host read)."""
+        if self.skip_nonfinite and getattr(self, "_steps_stale", False):
+            self._step = int(self._guard[0].item())
+            step_t = torch.tensor(float(self._step))
+            for p in self._params:
+                self.state[p]["step"] = step_t
+            self._steps_stale = False
+
+    def skipped_steps(self) -> int:
+        """Steps left out because their gradients were not finite (synchronises)."""
+        return int(self._guard[1].item())
+
+    def state_dict(self):
+        self._refresh_steps()
+        return super().state_dict()
+
     def load_state_dict(self, state_dict):
         sd = state_dict["state"]
         for i, p in enumerate(self._params):
@@ -117,6 +157,8 @@ class FlatAdamW(torch.optim.Optimizer):
             self.state[p]["exp_avg"].copy_(st["exp_avg"])
             self.state[p]["exp_avg_sq"].copy_(st["exp_avg_sq"])
             self._step = int(float(st["step"]))
+            self.state[p]["step"] = torch.tensor(float(self._step))
+        self._guard[0] = self._step
         for g_new, g_old in zip(self.param_groups, state_dict["param_groups"]):
             for k in ("lr", "betas", "eps", "weight_decay", "initial_lr"):
                 if k in g_old:
@@ -175,6 +217,8 @@ class FlatMuonAdamW(torch.optim.Optimizer):
         self.flat_v = torch.zeros(max(self.n_adamw, 1), dtype=torch.float32, device=dev)
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._step = 0
+        self.skip_nonfinite = False
+        self._guard = torch.zeros(2, dtype=torch.int32, device=dev)     # applied, skipped (skip_nonfinite steps)
         self._params, self._offsets = order, []
         off = 0
         with torch.no_grad():
@@ -237,34 +281,63 @@ class FlatMuonAdamW(torch.optim.Optimizer):
         self.sync_grads()
         lib, s = _lib.lib(), _lib.stream_handle()
         self._step += 1
+        guarded = self.skip_nonfinite
         ss = None
-        if max_norm and max_norm > 0:
+        if guarded or (max_norm and max_norm > 0):
             self._sumsq.zero_()
             _lib.check(lib.bd_sumsq_f32(_lib.ptr(self.flat_grad), self.numel, _lib.ptr(self._sumsq), s), "bd_sumsq_f32")
             ss = self._sumsq
         if self.n_adamw:
             g = self._adamw_group
             b1, b2 = g.get("betas", (0.9, 0.95))
-            bc1 = 1.0 - b1 ** self._step
-            bc2_sqrt = math.sqrt(1.0 - b2 ** self._step)
-            _lib.check(lib.bd_adamw_step(_lib.ptr(self.flat_param), _lib.ptr(self.flat_grad), _lib.ptr(self.flat_m),
-                                         _lib.ptr(self.flat_v), self.n_adamw, float(g["lr"]), float(b1), float(b2),
-                                         float(g.get("eps", 1e-8)), float(g.get("weight_decay", 0.0)), float(bc1),
-                                         float(bc2_sqrt), _lib.ptr(ss), float(max_norm or 0.0), s), "bd_adamw_step")
+            if guarded:
+                _lib.check(lib.bd_adamw_step_guarded(_lib.ptr(self.flat_param), _lib.ptr(self.flat_grad), _lib.ptr(self.flat_m),
+                                                     _lib.ptr(self.flat_v), self.n_adamw, float(g["lr"]), float(b1), float(b2),
+                                                     float(g.get("eps", 1e-8)), float(g.get("weight_decay", 0.0)),
+                                                     _lib.ptr(self._guard), _lib.ptr(ss), float(max_norm or 0.0), s),
+                           "bd_adamw_step_guarded")
+            else:
+                bc1 = 1.0 - b1 ** self._step
+                bc2_sqrt = math.sqrt(1.0 - b2 ** self._step)
+                _lib.check(lib.bd_adamw_step(_lib.ptr(self.flat_param), _lib.ptr(self.flat_grad), _lib.ptr(self.flat_m),
+                                             _lib.ptr(self.flat_v), self.n_adamw, float(g["lr"]), float(b1), float(b2),
+                                             float(g.get("eps", 1e-8)), float(g.get("weight_decay", 0.0)), float(bc1),
+                                             float(bc2_sqrt), _lib.ptr(ss), float(max_norm or 0.0), s), "bd_adamw_step")
         if self._classes:
             g = self._muon_group
+            muon_step = lib.bd_muon_step_guarded if guarded else lib.bd_muon_step
             for off, nb, rows, cols in self._classes:
-                _lib.check(lib.bd_muon_step(_lib.ptr(self.flat_param[off:]), _lib.ptr(self.flat_grad[off:]),
+                _lib.check(muon_step(_lib.ptr(self.flat_param[off:]), _lib.ptr(self.flat_grad[off:]),
                                             _lib.ptr(self.flat_m[off:]), _lib.ptr(self._ws), self._ws.numel(), nb, rows, cols,
                                             float(g["lr"]), float(g.get("weight_decay", 0.0)),
                                             float(g.get("momentum", 0.95)), int(bool(g.get("nesterov", True))),
                                             int(g.get("backend_steps", 5)), _lib.ptr(ss), float(max_norm or 0.0), s),
                            "bd_muon_step")
-        for p in self._params:
-            if "step" in self.state[p]:
-                self.state[p]["step"] = self._step
+        if guarded:
+            _lib.check(lib.bd_step_guard_update(_lib.ptr(self._guard), _lib.ptr(self._sumsq), s), "bd_step_guard_update")
+            self._steps_stale = True
+        else:
+            for p in self._params:
+                if "step" in self.state[p]:
+                    self.state[p]["step"] = self._step
         _lib.bump_weights_generation()
         return None
+
+    def _refresh_steps(self):
+        if self.skip_nonfinite and getattr(self, "_steps_stale", False):
+            self._step = int(self._guard[0].item())
+            for p in self._params:
+                if "step" in self.state[p]:
+                    self.state[p]["step"] = self._step
+            self._steps_stale = False
+
+    def skipped_steps(self) -> int:
+        """Steps left out because their gradients were not finite (synchronises)."""
+        return int(self._guard[1].item())
+
+    def state_dict(self):
+        self._refresh_steps()
+        return super().state_dict()
 
     def load_state_dict(self, state_dict):
         sd = state_dict["state"]
@@ -280,6 +353,8 @@ class FlatMuonAdamW(torch.optim.Optimizer):
                         self.state[p][k].copy_(st[k])
                 if "step" in st:
                     self._step = int(float(st["step"]))
+                    self.state[p]["step"] = self._step
+        self._guard[0] = self._step
         for g_new, g_old in zip(self.param_groups, state_dict["param_groups"]):
             for k in ("lr", "betas", "eps", "weight_decay", "initial_lr", "momentum", "nesterov", "backend_steps"):
                 if k in g_old:

@@ -4,8 +4,11 @@ Drop-in for ``src/training/trainer_backbone.py`` (``BackboneTrainer``, :61-715):
 constructor, ``train()`` / ``load_checkpoint()``, history dict, checkpoint dict layout
 (``epoch, global_step, model_state_dict, optimizer_state_dict, scheduler_state_dict, val_loss,
 best_val_loss, config``) and CSV files. Differences that follow from the native step:
-  * the denoiser always computes in bf16 on the MFMA path (``use_amp`` is accepted, autocast
-    and GradScaler are not needed: bf16 gradients are not scaled);
+  * the denoiser always computes in bf16 on the MFMA path. ``use_amp`` keeps what ``GradScaler`` contributes to
+    the reference's step (trainer_backbone.py:129,439-453): a step whose gradients hold an inf or NaN is skipped
+    and does not count for the bias corrections (``optimizer.skip_nonfinite``; decided on the device, without the
+    host synchronisation ``scaler.step`` makes). The scale factor itself is dropped: multiplying the loss by a power
+    of two and dividing the gradients by it again is exact in fp32;
   * AdamW + global-norm clipping are one fused kernel pair over a flat parameter buffer;
   * data parallelism = one process per GPU; the flat gradient buffer is all-reduced (mean) in
     a single RCCL call on optimizer steps only (accumulation micro-steps skip it, which is what
@@ -77,6 +80,7 @@ class BackboneTrainer:
         # AdamW or Muon + AdamW groups, driven by config["optimization"]["optimizer"] as in the reference
         # (trainer_backbone.py:164-178)
         self.optimizer, info = build_step1_backbone_optimizer(self.model, opt, self.learning_rate, self.weight_decay)
+        self.optimizer.skip_nonfinite = self.use_amp
         if self.is_main_process and info.get("type") == "muon_adamw":
             print("Using Muon+AdamW optimizer groups: "
                   f"muon_tensors={info.get('num_muon_tensors')}, adamw_tensors={info.get('num_adamw_tensors')}, "

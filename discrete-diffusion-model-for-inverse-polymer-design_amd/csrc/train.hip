@@ -944,8 +944,17 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float* __restrict__ m, float* __restrict__ v, long long n,
                                                     float lr, float beta1, float beta2, float eps, float wd,
                                                     float bc1, float bc2_sqrt, const float* __restrict__ gsumsq,
-                                                    float max_norm) {
+                                                    float max_norm, const int* __restrict__ guard, double beta1d,
+                                                    double beta2d) {
   float coef = 1.f;
+  if (guard != nullptr) {
+    // GradScaler.step semantics: non-finite gradients leave parameters, moments and the step count alone, and the
+    // bias corrections follow the count of APPLIED steps, which only the device knows without a host round trip
+    if (!isfinite(gsumsq[0])) return;
+    const double st = (double)(guard[0] + 1);
+    bc1 = (float)(1.0 - pow(beta1d, st));
+    bc2_sqrt = (float)sqrt(1.0 - pow(beta2d, st));
+  }
   if (gsumsq != nullptr && max_norm > 0.f) {
     const float norm = sqrtf(gsumsq[0]);
     coef = fminf(1.f, max_norm / (norm + 1e-6f));
@@ -975,8 +984,9 @@ __global__ __launch_bounds__(256) void muon_momentum_kernel(const float* __restr
                                                             unsigned short* __restrict__ X, float* __restrict__ sumsq,
                                                             const float* __restrict__ gsumsq, float max_norm,
                                                             float w_buf, float momentum, int nesterov, int rows,
-                                                            int cols) {
+                                                            int cols, int guarded) {
   __shared__ float part[4];
+  if (guarded && !isfinite(gsumsq[0])) return;
   float coef = 1.f;
   if (gsumsq != nullptr && max_norm > 0.f) coef = fminf(1.f, max_norm / (sqrtf(gsumsq[0]) + 1e-6f));
   const int b = blockIdx.y;
@@ -1026,7 +1036,9 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const unsigned shor
 
 // p <- p (1 - lr wd) - lr scale X   (X back in the parameter's own orientation)
 __global__ __launch_bounds__(256) void muon_apply_kernel(float* __restrict__ param, const unsigned short* __restrict__ X,
-                                                         float decay, float neg_step, int rows, int cols) {
+                                                         float decay, float neg_step, int rows, int cols,
+                                                         const float* __restrict__ guard_sumsq) {
+  if (guard_sumsq != nullptr && !isfinite(guard_sumsq[0])) return;
   const int b = blockIdx.y;
   const long long n = (long long)rows * cols;
   const bool tr = rows > cols;
@@ -1036,6 +1048,15 @@ __global__ __launch_bounds__(256) void muon_apply_kernel(float* __restrict__ par
     float pv = param[b * n + i];
     if (decay != 1.0f) pv = pv * decay;
     param[b * n + i] = pv + neg_step * u;
+  }
+}
+
+// guard[0] += the step was applied, guard[1] += it was skipped
+__global__ void guard_update_kernel(int* __restrict__ guard, const float* __restrict__ gsumsq) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const bool ok = isfinite(gsumsq[0]);
+    guard[0] += ok ? 1 : 0;
+    guard[1] += ok ? 0 : 1;
   }
 }
 
@@ -1381,8 +1402,30 @@ extern "C" int bd_adamw_step(float* params, const float* grads, float* exp_avg, 
   blocks = blocks > 4096 ? 4096 : blocks;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, grads,
                      exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bias_correction1,
-                     bias_correction2_sqrt, grad_sumsq, max_norm);
+                     bias_correction2_sqrt, grad_sumsq, max_norm, (const int*)nullptr, 0.0, 0.0);
   return bd_check_launch("bd_adamw_step");
+}
+
+extern "C" int bd_adamw_step_guarded(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                                     float lr, double beta1, double beta2, float eps, float weight_decay,
+                                     const int* guard, const float* grad_sumsq, float max_norm, void* stream) {
+  BD_REQUIRE(params && grads && exp_avg && exp_avg_sq && n >= 0, "bd_adamw_step_guarded: bad argument");
+  BD_REQUIRE(guard && grad_sumsq, "bd_adamw_step_guarded: needs the guard counters and the gradient sum of squares");
+  BD_REQUIRE(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0, "bd_adamw_step_guarded: betas outside [0, 1)");
+  bd_prof_scope prof(stream, (double)n * 28.0, BD_PROF_OPT);
+  if (n == 0) return BD_OK;
+  long long blocks = (n + 255) / 256;
+  blocks = blocks > 4096 ? 4096 : blocks;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, grads,
+                     exp_avg, exp_avg_sq, n, lr, (float)beta1, (float)beta2, eps, weight_decay, 1.f, 1.f, grad_sumsq,
+                     max_norm, guard, beta1, beta2);
+  return bd_check_launch("bd_adamw_step_guarded");
+}
+
+extern "C" int bd_step_guard_update(int* guard, const float* grad_sumsq, void* stream) {
+  BD_REQUIRE(guard && grad_sumsq, "bd_step_guard_update: null operand");
+  hipLaunchKernelGGL(guard_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, guard, grad_sumsq);
+  return bd_check_launch("bd_step_guard_update");
 }
 
 extern "C" int bd_cast_f32_to_bf16(const float* x, void* y, long long n, void* stream) {
@@ -1403,10 +1446,32 @@ extern "C" long long bd_muon_workspace_bytes(int nb, int rows, int cols) {
   return 2 * muon_align(2ll * nb * r * c) + 2 * muon_align(2ll * nb * r * r) + muon_align(4ll * nb);
 }
 
+static int muon_step_impl(float* params, const float* grads, float* momentum_buf, void* workspace,
+                          long long workspace_bytes, int nb, int rows, int cols, float lr, float weight_decay,
+                          float momentum, int nesterov, int ns_steps, const float* grad_sumsq, float max_norm,
+                          int guarded, void* stream);
+
 extern "C" int bd_muon_step(float* params, const float* grads, float* momentum_buf, void* workspace,
                             long long workspace_bytes, int nb, int rows, int cols, float lr, float weight_decay,
                             float momentum, int nesterov, int ns_steps, const float* grad_sumsq, float max_norm,
                             void* stream) {
+  return muon_step_impl(params, grads, momentum_buf, workspace, workspace_bytes, nb, rows, cols, lr, weight_decay,
+                        momentum, nesterov, ns_steps, grad_sumsq, max_norm, 0, stream);
+}
+
+extern "C" int bd_muon_step_guarded(float* params, const float* grads, float* momentum_buf, void* workspace,
+                                    long long workspace_bytes, int nb, int rows, int cols, float lr,
+                                    float weight_decay, float momentum, int nesterov, int ns_steps,
+                                    const float* grad_sumsq, float max_norm, void* stream) {
+  BD_REQUIRE(grad_sumsq != nullptr, "bd_muon_step_guarded: needs the gradient sum of squares");
+  return muon_step_impl(params, grads, momentum_buf, workspace, workspace_bytes, nb, rows, cols, lr, weight_decay,
+                        momentum, nesterov, ns_steps, grad_sumsq, max_norm, 1, stream);
+}
+
+static int muon_step_impl(float* params, const float* grads, float* momentum_buf, void* workspace,
+                          long long workspace_bytes, int nb, int rows, int cols, float lr, float weight_decay,
+                          float momentum, int nesterov, int ns_steps, const float* grad_sumsq, float max_norm,
+                          int guarded, void* stream) {
   BD_REQUIRE(params && grads && momentum_buf && workspace, "bd_muon_step: null operand");
   BD_REQUIRE(nb > 0 && nb <= 65535 && rows > 0 && cols > 0 && rows % 128 == 0 && cols % 128 == 0,
              "bd_muon_step: %d matrices of %d x %d (sizes must be multiples of 128)", nb, rows, cols);
@@ -1425,7 +1490,7 @@ extern "C" int bd_muon_step(float* params, const float* grads, float* momentum_b
   if (hipMemsetAsync(sumsq, 0, 4ll * nb, s) != hipSuccess) return bd_fail(BD_ERR_LAUNCH, "bd_muon_step: memset failed");
   const unsigned gx = (unsigned)((n + 1023) / 1024 < 1024 ? (n + 1023) / 1024 : 1024);
   hipLaunchKernelGGL(muon_momentum_kernel, dim3(gx, nb), dim3(256), 0, s, grads, momentum_buf, X, sumsq, grad_sumsq, max_norm,
-                     (float)(1.0 - (double)momentum), momentum, nesterov, rows, cols);
+                     (float)(1.0 - (double)momentum), momentum, nesterov, rows, cols, guarded);
   hipLaunchKernelGGL(muon_normalize_kernel, dim3(gx, nb), dim3(256), 0, s, X, sumsq, n);
   const int steps = ns_steps < 1 ? 1 : ns_steps;
   for (int it = 0; it < steps; ++it) {
@@ -1442,7 +1507,7 @@ extern "C" int bd_muon_step(float* params, const float* grads, float* momentum_b
   const float scale = rows > cols ? (float)rows / (float)cols : 1.0f;   // max(1, rows / cols)
   const float decay = weight_decay != 0.f ? (float)(1.0 - (double)lr * (double)weight_decay) : 1.0f;
   hipLaunchKernelGGL(muon_apply_kernel, dim3(gx, nb), dim3(256), 0, s, params, X, decay, (float)(-(double)lr * (double)scale),
-                     rows, cols);
+                     rows, cols, guarded ? grad_sumsq : (const float*)nullptr);
   return bd_check_launch("bd_muon_step");
 }
 

@@ -405,6 +405,18 @@ int bd_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_
                   float lr, float beta1, float beta2, float eps, float weight_decay, float bias_correction1,
                   float bias_correction2_sqrt, const float* grad_sumsq, float max_norm, void* stream);
 
+/* The update under GradScaler.step's rule (src/training/trainer_backbone.py:129,439-453: scaler.step skips
+ * optimizer.step when the unscaled gradients hold an inf or NaN, so parameters, moments and the per-parameter step
+ * count stay as they are): when grad_sumsq[0] is not finite the launch changes nothing. guard[0] = steps applied
+ * so far; the bias corrections are computed on the device from guard[0] + 1 (betas in double, as torch evaluates
+ * 1 - beta ** step), so no host round trip decides them. bd_step_guard_update, launched after every update of the
+ * step has been enqueued, adds the step to guard[0] (applied) or guard[1] (skipped). The scale factor itself is
+ * not kept: multiplying the loss by a power of two and dividing the gradients by it is exact in fp32. */
+int bd_adamw_step_guarded(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                          float lr, double beta1, double beta2, float eps, float weight_decay, const int* guard,
+                          const float* grad_sumsq, float max_norm, void* stream);
+int bd_step_guard_update(int* guard, const float* grad_sumsq, void* stream);
+
 /* Batched C_b = A_b W_b^T over `batch` problems of one shape (element strides sA, sW, sOut; bf16 in and
  * out, row stride N, N % 128 == 0, K % 64 == 0). aux == null: out = acc rounded. aux given (bf16, laid
  * out like out): out = rn(rn(beta * aux) + rn(alpha * rn(acc))), every step rounded to bf16 as the chain
@@ -424,6 +436,11 @@ int bd_muon_step(float* params, const float* grads, float* momentum_buf, void* w
                  long long workspace_bytes, int nb, int rows, int cols, float lr, float weight_decay,
                  float momentum, int nesterov, int ns_steps, const float* grad_sumsq, float max_norm,
                  void* stream);
+/* The same, leaving parameters and momentum alone when grad_sumsq[0] is not finite (see bd_adamw_step_guarded). */
+int bd_muon_step_guarded(float* params, const float* grads, float* momentum_buf, void* workspace,
+                         long long workspace_bytes, int nb, int rows, int cols, float lr, float weight_decay,
+                         float momentum, int nesterov, int ns_steps, const float* grad_sumsq, float max_norm,
+                         void* stream);
 
 /* Many fp32 -> bf16 copies in one launch: job j copies src [rows, cols] (contiguous) to dst[r * ld + c],
  * or, with transpose == 1, to dst[c * ld + r]; transpose == 2 copies fp32 to fp32 dst[r * ld + c] (stacked

@@ -164,6 +164,48 @@ def test_flat_muon_adamw_follows_reference_trajectory(gpu_device, tmp_path):
             assert torch.allclose(p, q, rtol=1e-5, atol=1e-7), n
 
 
+def test_guarded_muon_adamw_skips_nonfinite_steps(gpu_device):
+    """skip_nonfinite on the mixed optimizer: a NaN anywhere in the gradients leaves both groups' parameters and
+    states alone; the next finite step equals the step of an optimizer that never saw the bad one."""
+    dev = gpu_device
+    torch.manual_seed(3)
+    mk = lambda: [torch.nn.Parameter(t.clone().to(dev)) for t in base]
+    base = [torch.randn(128, 256), torch.randn(256, 128), torch.randn(128, 256), torch.randn(77)]
+    grads = [[torch.randn_like(t) for t in base] for _ in range(3)]
+    opts = []
+    for _ in range(2):
+        ps = mk()
+        opt = FlatMuonAdamW([dict(params=ps[:3], kind="muon", lr=0.02, weight_decay=0.01, momentum=0.95),
+                             dict(params=ps[3:], kind="adamw", lr=1e-3, betas=(0.9, 0.95), weight_decay=0.0)])
+        opt.skip_nonfinite = True
+        opts.append((opt, ps))
+    (a, pa), (b, pb) = opts
+    for step, gs in enumerate(grads):
+        for p, g in zip(pa, gs):
+            p.grad.copy_(g.to(dev))
+        a.step(); a.zero_grad()
+        if step == 0:          # optimizer b sees one poisoned step in between
+            for p, g in zip(pb, gs):
+                p.grad.copy_(g.to(dev))
+            b.step(); b.zero_grad()
+            snap = [p.detach().clone() for p in pb]
+            mom = b.flat_m.clone()
+            for p, g in zip(pb, gs):
+                p.grad.copy_(g.to(dev))
+            pb[1].grad[5, 5] = float("nan")
+            b.step(); b.zero_grad()
+            assert all(torch.equal(p.detach(), s) for p, s in zip(pb, snap)) and torch.equal(b.flat_m, mom)
+        else:
+            for p, g in zip(pb, gs):
+                p.grad.copy_(g.to(dev))
+            b.step(); b.zero_grad()
+    # no clipping here: the gradient norm is summed with atomics, and a last-bit difference of the clip factor is
+    # amplified by the bf16 Newton-Schulz iterations; without it the two trajectories are the same bits
+    assert all(torch.equal(x.detach(), y.detach()) for x, y in zip(pa, pb))
+    assert b.skipped_steps() == 1 and a.skipped_steps() == 0
+    assert b.state_dict()["state"][3]["step"] == 3
+
+
 def test_training_steps_with_muon_reduce_the_loss(gpu_device):
     """End to end: the diffusion training step with the Muon + AdamW optimizer learns a fixed batch."""
     from bidiff.model.diffusion import DiscreteMaskingDiffusion

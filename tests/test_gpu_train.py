@@ -252,6 +252,57 @@ def test_fused_adamw_with_clip_matches_torch(gpu_device):
     assert set(sd["state"][0]) >= {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 5.0
 
 
+@pytest.mark.parametrize("bad", [float("inf"), float("nan")])
+def test_guarded_adamw_follows_gradscaler_skip_rule(gpu_device, bad):
+    """skip_nonfinite = GradScaler.unscale_ + clip_grad_norm_ + GradScaler.step around torch.optim.AdamW
+    (reference trainer_backbone.py:441-453): a step with a non-finite gradient changes nothing and does not count
+    for the bias corrections of the steps after it."""
+    dev = gpu_device
+    g = torch.Generator().manual_seed(16)
+    shapes = [(37, 5), (128,), (64, 64)]
+    ps = [torch.nn.Parameter(torch.randn(*s, generator=g).to(dev)) for s in shapes]
+    rs = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ps]
+    opt = FlatAdamW(ps, lr=3e-3, weight_decay=0.05)
+    opt.skip_nonfinite = True
+    ref = torch.optim.AdamW(rs, lr=3e-3, weight_decay=0.05)
+    scaler = torch.amp.GradScaler("cpu", enabled=True)
+    for step in range(7):
+        scaler.scale(torch.ones(1))
+        for i, (p, r) in enumerate(zip(ps, rs)):
+            gr = torch.randn(*r.shape, generator=g) * (10.0 if step % 2 == 0 else 0.01)
+            if step in (1, 4) and i == 2:
+                gr[3, 7] = bad
+            r.grad = gr * scaler.get_scale()
+            p.grad.copy_(gr.to(dev))
+        before = [p.detach().clone() for p in ps]
+        scaler.unscale_(ref)
+        torch.nn.utils.clip_grad_norm_(rs, 1.0)
+        scaler.step(ref)
+        scaler.update()
+        opt.step(max_norm=1.0)
+        opt.zero_grad()
+        for p, r, b in zip(ps, rs, before):
+            assert torch.isfinite(p).all()
+            assert (p.detach().cpu() - r.detach()).abs().max().item() < 2e-6
+            if step in (1, 4):
+                assert torch.equal(p.detach(), b)
+    assert opt.skipped_steps() == 2
+    sd = opt.state_dict()
+    assert float(sd["state"][0]["step"]) == 5.0 == float(ref.state[rs[0]]["step"])
+    # a restored optimizer continues the count of applied steps
+    ps2 = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt2 = FlatAdamW(ps2, lr=3e-3, weight_decay=0.05)
+    opt2.skip_nonfinite = True
+    opt2.load_state_dict(sd)
+    for p, p2, r in zip(ps, ps2, rs):
+        gr = torch.randn(*r.shape, generator=g)
+        r.grad = gr.clone(); p.grad.copy_(gr.to(dev)); p2.grad.copy_(gr.to(dev))
+    ref.step(); opt.step(); opt2.step()
+    for p, p2, r in zip(ps, ps2, rs):
+        assert (p.detach().cpu() - r.detach()).abs().max().item() < 2e-6
+        assert torch.equal(p.detach(), p2.detach())
+
+
 def _grad_setup(name, dev, B=6, L=24):
     cfg = RI.BACKBONE_CFGS[name]
     torch.manual_seed(7)
