@@ -342,13 +342,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
 // 128 x 128 each, 32x32x16 MFMAs, fp32 accumulators in 256 registers per lane, one wave per SIMD.
 // The 64 x 64 wave tile above reads 1 KiB of LDS per 2 MFMAs and saturates the LDS pipe together
 // with the MFMA pipe; a 128 x 128 wave tile reads half as much per flop.
-//  * Operands reach LDS by LDS-DMA in FRAGMENT order: a 1-KiB fragment is, lane by lane, the operand
-//    of one MFMA (lane = 32 kh + r holds row r, k = 16 q + 8 kh .. +7), so LDS reads are lane-linear
-//    and conflict-free without a swizzle. The lane's global address does the gather.
+//  * Operands reach LDS by LDS-DMA as whole cache lines: a 1-KiB piece is 8 rows x 128 B (BK = 64), so a DMA
+//    instruction touches 8 lines and uses all of each (a piece laid out as one MFMA operand, 32 rows x 32 B,
+//    touches 32 lines for a quarter each, and the CU's line rate then paces the kernel). Inside a row the eight
+//    16-byte k-chunks are stored at slot chunk ^ ((row >> 1) & 7): the operand read of an MFMA (32 rows, one
+//    k-chunk per half-wave) then covers every bank once per 16 lanes.
 //  * Weight rows are permuted inside a 32-row tile (MFMA row rho <-> column 16 ((rho >> 2) & 1) +
 //    4 (rho >> 3) + (rho & 3)) so that a lane's 16 accumulators of a tile are 16 consecutive n.
 //  * Two 64-KiB stages (BK = 64): the next stage's DMA runs during this stage's 64 MFMAs per wave.
 //    LDS reads are inline asm with their own waits (the compiler would wait for the DMA in flight).
+//  * What paces it (8192^3, one box): 1.07 ms; without the DMA 0.84, without the operand reads 1.00, with neither
+//    0.59 (the matrix cores alone, 1.87 PFLOP/s: the chip's sustained clock under this load). A stage is 64 KB per
+//    CU, and a CU takes in about 25 B per clock at best through its vector memory path: 2.6 k cycles per stage
+//    against 2.0 k of MFMAs, so the stream, not the issue order, sets the k-step; the tile order above keeps the
+//    stream in L2 (worth 8 %).
 // -------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(1))) void g256_glb;
 typedef __attribute__((address_space(3))) void g256_lds;
@@ -374,29 +381,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int q = nwg >> 3, rr = nwg & 7, xcd = orig & 7;
     tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
   }
-  const int tiles_n = p.Npad >> 8;
-  const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
+  // Tiles in groups of 8 tile rows, column by column inside a group: the 32 workgroups that an XCD runs at a time
+  // (consecutive logical tiles) then cover 8 x 4 tiles and share 12 operand panels in their L2 instead of the 33
+  // of a 1 x 32 strip.
+  const int tiles_n = p.Npad >> 8, tiles_m = (p.M + 255) >> 8;
+  const int per_group = 8 * tiles_n, group = tile / per_group;
+  const int rows_here = min(tiles_m - 8 * group, 8);
+  const int in_group = tile - group * per_group;
+  const int m0 = (8 * group + in_group % rows_here) * 256, n0 = (in_group / rows_here) * 256;
   const int K = p.K, nk = K / 64;
 
-  // DMA: wave w moves the fragments with k16 index q = w of all 16 (part, tile) pairs of a stage
-  const int nperm = 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);
-  const unsigned short* gw = p.W + (size_t)(n0 + nperm) * K + 16 * wave + 8 * kh;
-  const unsigned short* garow[8];
+  // DMA: a 1-KiB piece = 8 operand rows x 128 B (the stage's 64 k-values of each row, whole cache lines). Lane i
+  // lands at byte 16 i of the piece: row i / 8, 16-byte slot i % 8, and fetches the row's k-chunk
+  // (slot ^ swizzle(row)), so that the MFMA operand reads below (32 rows x one k-chunk) spread over all banks.
+  // LDS row rho of a 32-row weight tile holds weight row n0 + 32 tile + nperm(rho). Wave w moves pieces 8 w .. 8 w + 7
+  // of either part.
+  // A piece costs three instructions: M0 = LDS destination, then the load with a scalar base (the tile's rows at
+  // this k-step) and one 32-bit lane offset per piece number. (The builtin with a per-lane 64-bit pointer makes the
+  // compiler emit 64-bit vector adds per piece: 57 cycles of issue per piece instead of 20, on a wave whose SIMD has
+  // no other wave to run.)
+  unsigned voffw[8], voffa[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    int am = m0 + 32 * t + r;
+    const int row = 8 * (8 * wave + t) + (lane >> 3);         // 0 .. 255 inside the part
+    const int rho = row & 31, tl = row >> 5;
+    const int chunk = (lane & 7) ^ ((rho >> 1) & 7);
+    const int np = 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3);
+    voffw[t] = (unsigned)(((32 * tl + np) * K + 8 * chunk) * 2);
+    int am = m0 + row;
     am = am < p.M ? am : p.M - 1;
-    garow[t] = p.A + (size_t)am * K + 16 * wave + 8 * kh;
+    voffa[t] = (unsigned)(((am - m0) * K + 8 * chunk) * 2);
+    asm volatile("" : "+v"(voffw[t]), "+v"(voffa[t]));
   }
-  auto issue = [&](int s) {
-    unsigned char* st = smem256 + (s & 1) * G256_STAGE + wave * 1024;
-    const int k0 = s * 64;
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-      __builtin_amdgcn_global_load_lds((g256_glb*)(gw + (size_t)(32 * t) * K + k0), (g256_lds*)(st + t * 4096), 16, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-      __builtin_amdgcn_global_load_lds((g256_glb*)(garow[t] + k0), (g256_lds*)(st + G256_PART + t * 4096), 16, 0, 0);
+  const unsigned char* const wtile = (const unsigned char*)(p.W + (size_t)n0 * K);
+  const unsigned char* const atile = (const unsigned char*)(p.A + (size_t)m0 * K);
+  const unsigned ldsw = (unsigned)(size_t)(g256_lds*)smem256 + wave * 8192;
+  // piece i of stage s: i < 8 weight rows, else activation rows
+  auto piece = [&](int s, int i) {
+    const unsigned st = ldsw + (s & 1) * G256_STAGE;
+    const unsigned char* src = (i < 8 ? wtile : atile) + (size_t)s * 128;
+    asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"
+                 ::"s"(st), "i"((i & 7) * 1024 + (i < 8 ? 0 : G256_PART)), "v"(i < 8 ? voffw[i & 7] : voffa[i & 7]), "s"(src)
+                 : "memory", "m0", "scc");
   };
 
   f32x16 acc[4][4];
@@ -409,24 +435,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       asm volatile("" : "+a"(acc[i][j]));
     }
 
-  // fragment addresses of this wave inside a stage: W tiles 4 wn + j, A tiles 4 wm + j, k16 index q
-  const unsigned lds0 = (unsigned)(size_t)(g256_lds*)smem256 + lane * 16;
+  // operand addresses of this wave inside a stage: W tiles 4 wn + j, A tiles 4 wm + j (4 KiB each: 32 rows x 128 B);
+  // lane (r, kh) reads row r, k-chunk 2 q + kh, which sits in slot (2 q + kh) ^ swizzle(r)
+  const unsigned lds0 = (unsigned)(size_t)(g256_lds*)smem256 + r * 128;
   const unsigned wbase = lds0 + (4 * wn) * 4096, abase = lds0 + G256_PART + (4 * wm) * 4096;
+  unsigned qoff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) qoff[q] = (unsigned)(((2 * q + kh) ^ ((r >> 1) & 7)) * 16);
 
-  issue(0);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) piece(0, i);
   for (int s = 0; s < nk; ++s) {
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (s + 1 < nk) issue(s + 1);
+    const bool more = s + 1 < nk;
     const unsigned so = (s & 1) * G256_STAGE;
     bf16x8 fw[2][4], fa[2][4];
-    auto reads = [&](int q, int b) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fw[b][j]) : "v"(wbase + so + q * 1024), "i"(j * 4096));
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[b][j]) : "v"(abase + so + q * 1024), "i"(j * 4096));
-      }
+    // one operand read: i < 4 weight tile i, else activation tile i - 4, k16 index q, into register set b
+    auto read1 = [&](int q, int b, int i) {
+      if (i < 4)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fw[b][i & 3]) : "v"(wbase + so + qoff[q]), "i"((i & 3) * 4096));
+      else
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[b][i & 3]) : "v"(abase + so + qoff[q]), "i"((i & 3) * 4096));
     };
-    reads(0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) read1(0, 0, i);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int b = q & 1;
@@ -434,14 +466,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       asm volatile("s_waitcnt lgkmcnt(0)"
                    : "+v"(fw[b][0]), "+v"(fw[b][1]), "+v"(fw[b][2]), "+v"(fw[b][3]), "+v"(fa[b][0]), "+v"(fa[b][1]),
                      "+v"(fa[b][2]), "+v"(fa[b][3]));
-      if (q + 1 < 4) reads(q + 1, b ^ 1);
-      __builtin_amdgcn_sched_barrier(0);      // the next step's reads go out before this step's MFMAs
+      // One wave per SIMD issues in order: whatever is not placed between two MFMAs adds to the step instead of
+      // running in the 24 cycles an MFMA leaves free. So the next step's eight operand reads follow the first eight
+      // MFMAs one by one, and four of the next stage's 16 pieces follow every second MFMA of the other eight (the
+      // stage's buffer was last read before this step's barrier).
 #pragma unroll
       for (int jn = 0; jn < 4; ++jn)
 #pragma unroll
-        for (int jm = 0; jm < 4; ++jm)
+        for (int jm = 0; jm < 4; ++jm) {
+          const int i = 4 * jn + jm;
           acc[jn][jm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[b][jn], fa[b][jm], acc[jn][jm], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+          if (i < 8 && q + 1 < 4) read1(q + 1, b ^ 1, i);
+          if (i >= 8 && (i & 1) && more) piece(s + 1, 4 * q + ((i - 8) >> 1));
+          __builtin_amdgcn_sched_barrier(0);
+        }
     }
   }
 
