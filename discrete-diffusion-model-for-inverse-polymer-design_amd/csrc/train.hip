@@ -524,6 +524,8 @@ constexpr int AROW = 256;   // LDS row stride in bytes
 template <int DH>
 __device__ __forceinline__ void stage_rows(unsigned char* dst, const unsigned short* src, size_t row_stride,
                                            int first, int limit, int tid, unsigned groups = 0xfu) {
+  // (holding all of a thread's pieces in registers before the first LDS store, to pay one memory latency per tile
+  // instead of one per piece, spills in these kernels: 43 -> 185 us)
   constexpr int CPR = DH / 8;
   for (int idx = tid; idx < AT * CPR; idx += 256) {
     const int row = idx / CPR, ch = idx % CPR;
@@ -618,6 +620,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned shor
 #pragma unroll
       for (int e = 0; e < 8; ++e) { pv[s4][e] = 0.f; dv[s4][e] = 0.f; }
       if (!((live >> s4) & 1u)) continue;
+      bd_philox_out w;      // one block = the lane's eight keys of this group (both halves)
+      if (DROP) w = bd_drop_block(drop, (uint32_t)(((size_t)b * H + h) * Ls + qr), (uint32_t)((kt0 + 32 * s4 + 8 * g) >> 3));
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int krow = 32 * s4 + 8 * (c >> 2) + 4 * half + (c & 3);
@@ -632,7 +636,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned shor
         const int kb = 32 * s4 + 8 * g + 4 * half;
         const unsigned int m4 = *(const unsigned int*)(Ms + kb);
         if (DROP) {   // dP = (dO V^T) * keep / (1 - p)
-          const bd_philox_out w = bd_drop_block(drop, (uint32_t)(((size_t)b * H + h) * Ls + qr), (uint32_t)((kt0 + kb) >> 3));
 #pragma unroll
           for (int r = 0; r < 4; ++r) dp[r] *= bd_drop_factor(drop, w, 4 * half + r);
         }
@@ -751,23 +754,41 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const unsigned sho
     }
     __syncthreads();
     if (!wave_live) continue;
-    // keep decisions of the lane's key against this lane's 32 queries of the tile, one Philox block
-    // per query (the block holds eight neighbouring KEYS); a rolled loop keeps the registers free
+    // 32-query groups past the end of the sequence have P = 0 and dS = 0: not multiplied
+    const int ngrp = min(4, (L - qt0 + 31) >> 5);
+    // Keep decisions of the lane's key against this lane's 32 queries of the tile (bit i <-> query 8 g + 32 (i >> 3) +
+    // (i & 7)). One Philox block per query holds the decisions of eight neighbouring KEYS, and the eight lanes that
+    // own those keys (same g, same c >> 3) need the same 32 blocks: each evaluates four of them, reduces every block
+    // to its eight keep bits, and the lanes exchange the bytes.
     uint32_t keepbits = 0u;
     if (DROP) {
       const uint32_t prow0 = (uint32_t)(((size_t)b * H + h) * Ls + qt0 + 8 * g);
-#pragma nounroll
-      for (int i = 0; i < 32; ++i) {
-        const bd_philox_out w = bd_drop_block(drop, prow0 + 32 * (i >> 3) + (i & 7), (uint32_t)(kr >> 3));
-        const uint32_t lo = (kr & 2) ? w.v[1] : w.v[0], hi = (kr & 2) ? w.v[3] : w.v[2];
-        const uint32_t word = (kr & 4) ? hi : lo;
-        keepbits |= (uint32_t)(((word >> (16 * (kr & 1))) & 0xffffu) >= drop.thr) << i;
+      const uint32_t kblk = (uint32_t)((k0 + c) >> 3);
+      const int j = c & 7;
+      uint32_t mine = 0u;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int i = 4 * j + t;
+        if ((i >> 3) >= ngrp) continue;
+        const bd_philox_out w = bd_drop_block(drop, prow0 + 32 * (i >> 3) + (i & 7), kblk);
+        uint32_t byte = 0u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          byte |= (uint32_t)(((w.v[e >> 1] >> (16 * (e & 1))) & 0xffffu) >= drop.thr) << e;
+        mine |= byte << (8 * t);
+      }
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const uint32_t wv = __shfl(mine, (lane & ~7) | jj, 64) >> ((k0 + c) & 7);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) keepbits |= ((wv >> (8 * t)) & 1u) << (4 * jj + t);
       }
     }
     bf16x8 pf[4], dsf[4];
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
       bf16x8 fp, fd;
+      if (s4 >= ngrp) continue;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int qrow = 32 * s4 + 8 * (c >> 2) + 4 * half + (c & 3);
@@ -797,6 +818,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const unsigned sho
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
+        if (s4 >= ngrp) continue;
         const int r0 = 32 * s4 + 8 * g + q4, ch = 2 * dt + (p4 >> 1);
         union { struct { s16x4 a, b; } s; bf16x8 v; } u;
         u.s.a = lds_read_tr(Ds + tile_off(r0, ch) + 8 * (p4 & 1));
