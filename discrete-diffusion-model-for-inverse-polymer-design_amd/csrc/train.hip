@@ -111,11 +111,9 @@ __global__ __launch_bounds__(512) void layernorm_bwd_kernel(const unsigned short
   // rpw rows per wave (host: enough workgroups to fill the chip), walked two at a time so that the second row's
   // loads and reductions overlap the first's (a wave that handles its rows one after another spends its time
   // waiting: each row is a load, two dependent wave reductions and a store)
-  extern __shared__ float red[];   // [2][d]
+  extern __shared__ float red[];   // [8 waves][2][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = d / 4;
-  for (int i = threadIdx.x; i < 2 * d; i += 512) red[i] = 0.f;
-  __syncthreads();
   f32x4 gm[NV], ag[NV], ab[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
@@ -198,16 +196,22 @@ __global__ __launch_bounds__(512) void layernorm_bwd_kernel(const unsigned short
       }
     }
   }
+  // the eight waves' sums side by side in LDS (plain stores), then one thread per column adds them up: LDS atomics
+  // from eight waves on the same 2 d addresses serialise
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int i = lane + 64 * j;
     if (i < nv) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        atomicAdd(red + 4 * i + e, ag[j][e]);
-        atomicAdd(red + d + 4 * i + e, ab[j][e]);
-      }
+      ((f32x4*)(red + (size_t)wave * 2 * d))[i] = ag[j];
+      ((f32x4*)(red + (size_t)wave * 2 * d + d))[i] = ab[j];
     }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * d; i += 512) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) t += red[(size_t)w * 2 * d + i];
+    red[i] = t;       // column i is read and written by this thread only
   }
   __syncthreads();
   for (int i = threadIdx.x; i < d; i += 512) {
@@ -1152,31 +1156,35 @@ extern "C" int bd_layernorm_bwd_cast(const void* dy_bf16, const float* x, const 
                                      const float* dres, float* dx, float* dgamma, float* dbeta, int M, int d,
                                      void* dx_bf16, const bd_dropout* drop, unsigned site, void* stream) {
   BD_REQUIRE(dy_bf16 && x && stats && gamma && dx && dgamma && dbeta, "bd_layernorm_bwd: null operand");
-  BD_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 4096, "bd_layernorm_bwd: bad shape M=%d d=%d", M, d);
+  BD_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 2048, "bd_layernorm_bwd: bad shape M=%d d=%d", M, d);
   bd_drop_args da;
   BD_REQUIRE(bd_drop_make(drop, site, &da), "bd_layernorm_bwd: dropout p=%g outside [0, 1)", (double)drop->p);
   BD_REQUIRE(da.thr == 0u || (dx_bf16 != nullptr && d % 8 == 0), "bd_layernorm_bwd: dropout applies to the bf16 output (d %% 8 == 0)");
-  // Rows per wave: about 320 workgroups of 8 waves, at most 16, an even number above 1. More workgroups mean more
-  // same-address atomics on the 2 d parameter-gradient sums (they retire one after another at the memory side:
-  // 10 k rows take 63 us at 1 row per wave, 30 us at 4 or 8), fewer mean idle CUs. A second stage that sums
-  // per-workgroup partial results needs a device-scope fence per workgroup, which on this part writes the
-  // workgroup's XCD L2 back and costs far more (150 us) than the atomics it saves.
+  // Rows per wave: about 320 workgroups of 8 waves, at most 16, an even number above 1. Every workgroup ends with
+  // the sum over its eight waves and 2 d atomics, a fixed cost per workgroup, so more, smaller workgroups are slower
+  // (10 k rows: 63 us at 1 row per wave, 30 us at 4 or 8) and fewer leave CUs idle. Neither a second launch that
+  // sums per-workgroup partial results (40 us against 25) nor a last-workgroup reduction behind a device-scope fence
+  // (150 us: the fence writes the XCD's L2 back) beats the atomics.
   int rpw = M / (8 * 320);
   rpw = rpw < 1 ? 1 : (rpw > 16 ? 16 : rpw);
   if (rpw > 1) rpw &= ~1;
   dim3 grid((M + 8 * rpw - 1) / (8 * rpw)), block(512);
-  const size_t lds = 2 * (size_t)d * sizeof(float);
+  const size_t lds = 16 * (size_t)d * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   const unsigned short* dy = (const unsigned short*)dy_bf16;
   unsigned short* ob = (unsigned short*)dx_bf16;
   const int nv = (d / 4 + 63) / 64;
   bd_prof_scope prof(stream, (double)M * d * (2.0 + 4.0 + 4.0 + 4.0 + (dx_bf16 ? 2.0 : 0.0)), BD_PROF_LN);
-#define BD_LNB(NV) hipLaunchKernelGGL(layernorm_bwd_kernel<NV>, grid, block, lds, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d, ob, da, rpw)
+#define BD_LNB(NV)                                                                                              \
+  do {                                                                                                          \
+    BD_SET_MAX_LDS((layernorm_bwd_kernel<NV>), lds);                                                            \
+    hipLaunchKernelGGL(layernorm_bwd_kernel<NV>, grid, block, lds, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d, ob, \
+                       da, rpw);                                                                                \
+  } while (0)
   if (nv <= 1) BD_LNB(1);
   else if (nv <= 2) BD_LNB(2);
   else if (nv <= 4) BD_LNB(4);
-  else if (nv <= 8) BD_LNB(8);
-  else BD_LNB(16);
+  else BD_LNB(8);
 #undef BD_LNB
   return bd_check_launch("bd_layernorm_bwd");
 }
