@@ -248,6 +248,12 @@ def train_bench(dev, rank, world, steps, warmup, cpu_steps, threads, batch=256, 
            "roofline": {"bound": "mfma", "kernel": "whole training step (forward + backward + clip + AdamW)",
                         "achieved": tfl, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / MFMA_BF16_PEAK_TFLOPS,
                         "flops_per_step": flops_step, "traffic": None,
+                        # the same step measured in the work of the padded layout the reference computes (every one of
+                        # the B * L rows): what the step retires of THAT workload per second; the packed path does a
+                        # third of these flops, so this is a throughput equivalent, not matrix-core utilisation
+                        "padded_layout_equivalent": {"flops_per_step": flops_all_rows,
+                                                     "achieved": flops_all_rows / (ms_step * 1e-3) / 1e12,
+                                                     "frac": flops_all_rows / (ms_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS},
                         "dominant_kernel": roofline_of(table) if table else None},
            "kernels": named(table), "profiled_steps": n_prof}
     if cpu_steps > 0 and world == 1 and rank == 0:

@@ -342,24 +342,26 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
 // 128 x 128 each, 32x32x16 MFMAs, fp32 accumulators in 256 registers per lane, one wave per SIMD.
 // The 64 x 64 wave tile above reads 1 KiB of LDS per 2 MFMAs and saturates the LDS pipe together
 // with the MFMA pipe; a 128 x 128 wave tile reads half as much per flop.
-//  * Operands reach LDS by LDS-DMA as whole cache lines: a 1-KiB piece is 8 rows x 128 B (BK = 64), so a DMA
-//    instruction touches 8 lines and uses all of each (a piece laid out as one MFMA operand, 32 rows x 32 B,
-//    touches 32 lines for a quarter each, and the CU's line rate then paces the kernel). Inside a row the eight
-//    16-byte k-chunks are stored at slot chunk ^ ((row >> 1) & 7): the operand read of an MFMA (32 rows, one
-//    k-chunk per half-wave) then covers every bank once per 16 lanes.
+//  * Operands reach LDS by LDS-DMA as whole 64-byte memory requests: a 1-KiB piece is 16 rows x 64 B (BK = 32), so
+//    a DMA instruction makes 16 requests and uses all of each (a piece laid out as one MFMA operand, 32 rows x 32 B,
+//    makes 32 for half of each, and the CU's request rate then paces the kernel). Inside a row the four 16-byte
+//    k-chunks are stored at slot chunk ^ ((row >> 2) & 3): the operand read of an MFMA (32 rows, one k-chunk per
+//    half-wave) then covers every bank once per 16 lanes.
 //  * Weight rows are permuted inside a 32-row tile (MFMA row rho <-> column 16 ((rho >> 2) & 1) +
 //    4 (rho >> 3) + (rho & 3)) so that a lane's 16 accumulators of a tile are 16 consecutive n.
-//  * Two 64-KiB stages (BK = 64): the next stage's DMA runs during this stage's 64 MFMAs per wave.
-//    LDS reads are inline asm with their own waits (the compiler would wait for the DMA in flight).
-//  * What paces it (8192^3, one box): 1.07 ms; without the DMA 0.84, without the operand reads 1.00, with neither
-//    0.59 (the matrix cores alone, 1.87 PFLOP/s: the chip's sustained clock under this load). A stage is 64 KB per
-//    CU, and a CU takes in about 25 B per clock at best through its vector memory path: 2.6 k cycles per stage
-//    against 2.0 k of MFMAs, so the stream, not the issue order, sets the k-step; the tile order above keeps the
-//    stream in L2 (worth 8 %).
+//  * Four 32-KiB stages (BK = 32), two to three of them in flight; counted vmcnt waits (loads return in order), one
+//    barrier per stage in the middle of a step. LDS reads are inline asm with their own waits (the compiler would
+//    wait for the DMA in flight).
+//  * What paces it (8192^3, one box, measured on the two-stage BK = 64 form): 1.07 ms; without the DMA 0.84, without
+//    the operand reads 1.00, with neither 0.59 (the matrix cores alone, 1.87 PFLOP/s: the chip's sustained clock
+//    under this load). 64 KB per CU per 64 k-values against about 25 B per clock that a CU takes in at best through
+//    its vector memory path: 2.6 k cycles against 2.0 k of MFMAs, so the stream, not the issue order, sets the pace;
+//    the tile order above keeps the stream in L2 (worth 8 %), the deeper ring is worth 1-6 %. K = 8192 also pays for
+//    its power-of-two row stride (all rows of a piece in one memory channel): K = 8320 runs at 1.18 PFLOP/s, 1.05 at 8192.
 // -------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(1))) void g256_glb;
 typedef __attribute__((address_space(3))) void g256_lds;
-constexpr int G256_STAGE = 65536, G256_PART = 32768;
+constexpr int G256_STAGE = 32768, G256_PART = 16384;   // four stages of BK = 32
 
 template <int EPI, bool DROP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm256_kernel(GemmArgs p) {
@@ -389,23 +391,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int rows_here = min(tiles_m - 8 * group, 8);
   const int in_group = tile - group * per_group;
   const int m0 = (8 * group + in_group % rows_here) * 256, n0 = (in_group / rows_here) * 256;
-  const int K = p.K, nk = K / 64;
+  const int K = p.K, nk = K / 32;
 
-  // DMA: a 1-KiB piece = 8 operand rows x 128 B (the stage's 64 k-values of each row, whole cache lines). Lane i
-  // lands at byte 16 i of the piece: row i / 8, 16-byte slot i % 8, and fetches the row's k-chunk
-  // (slot ^ swizzle(row)), so that the MFMA operand reads below (32 rows x one k-chunk) spread over all banks.
-  // LDS row rho of a 32-row weight tile holds weight row n0 + 32 tile + nperm(rho). Wave w moves pieces 8 w .. 8 w + 7
-  // of either part.
+  // Four stages of BK = 32 (32 KB each: 256 weight rows and 256 activation rows x 64 B), so that two to three stages
+  // are in flight at any time: with two stages of BK = 64 every k-step began with nothing in flight (the whole next
+  // stage is issued and awaited inside one step), and the CU's ingest path idled while the queue refilled.
+  // DMA: a 1-KiB piece = 16 operand rows x 64 B (one 64-byte memory request per row). Lane i lands at byte 16 i of
+  // the piece: row i / 4, 16-byte slot i % 4, and fetches the row's k-chunk (slot ^ ((row >> 2) & 3)), so that the
+  // MFMA operand reads below (32 rows x one k-chunk) cover every bank once per 16 lanes. LDS row rho of a 32-row
+  // weight tile holds weight row n0 + 32 tile + nperm(rho). Wave w moves pieces 4 w .. 4 w + 3 of either part.
   // A piece costs three instructions: M0 = LDS destination, then the load with a scalar base (the tile's rows at
   // this k-step) and one 32-bit lane offset per piece number. (The builtin with a per-lane 64-bit pointer makes the
   // compiler emit 64-bit vector adds per piece: 57 cycles of issue per piece instead of 20, on a wave whose SIMD has
   // no other wave to run.)
-  unsigned voffw[8], voffa[8];
+  unsigned voffw[4], voffa[4];
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    const int row = 8 * (8 * wave + t) + (lane >> 3);         // 0 .. 255 inside the part
+  for (int t = 0; t < 4; ++t) {
+    const int row = 16 * (4 * wave + t) + (lane >> 2);         // 0 .. 255 inside the part
     const int rho = row & 31, tl = row >> 5;
-    const int chunk = (lane & 7) ^ ((rho >> 1) & 7);
+    const int chunk = (lane & 3) ^ ((rho >> 2) & 3);
     const int np = 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3);
     voffw[t] = (unsigned)(((32 * tl + np) * K + 8 * chunk) * 2);
     int am = m0 + row;
@@ -415,13 +419,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   const unsigned char* const wtile = (const unsigned char*)(p.W + (size_t)n0 * K);
   const unsigned char* const atile = (const unsigned char*)(p.A + (size_t)m0 * K);
-  const unsigned ldsw = (unsigned)(size_t)(g256_lds*)smem256 + wave * 8192;
-  // piece i of stage s: i < 8 weight rows, else activation rows
+  const unsigned ldsw = (unsigned)(size_t)(g256_lds*)smem256 + wave * 4096;
+  // piece i of stage s: i < 4 weight rows, else activation rows
   auto piece = [&](int s, int i) {
-    const unsigned st = ldsw + (s & 1) * G256_STAGE;
-    const unsigned char* src = (i < 8 ? wtile : atile) + (size_t)s * 128;
+    const unsigned st = ldsw + (s & 3) * G256_STAGE;
+    const unsigned char* src = (i < 4 ? wtile : atile) + (size_t)s * 64;
     asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"
-                 ::"s"(st), "i"((i & 7) * 1024 + (i < 8 ? 0 : G256_PART)), "v"(i < 8 ? voffw[i & 7] : voffa[i & 7]), "s"(src)
+                 ::"s"(st), "i"((i & 3) * 1024 + (i < 4 ? 0 : G256_PART)), "v"(i < 4 ? voffw[i & 3] : voffa[i & 3]), "s"(src)
                  : "memory", "m0", "scc");
   };
 
@@ -435,52 +439,77 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       asm volatile("" : "+a"(acc[i][j]));
     }
 
-  // operand addresses of this wave inside a stage: W tiles 4 wn + j, A tiles 4 wm + j (4 KiB each: 32 rows x 128 B);
-  // lane (r, kh) reads row r, k-chunk 2 q + kh, which sits in slot (2 q + kh) ^ swizzle(r)
-  const unsigned lds0 = (unsigned)(size_t)(g256_lds*)smem256 + r * 128;
-  const unsigned wbase = lds0 + (4 * wn) * 4096, abase = lds0 + G256_PART + (4 * wm) * 4096;
-  unsigned qoff[4];
+  // operand addresses of this wave inside a stage: W tiles 4 wn + j, A tiles 4 wm + j (2 KiB each: 32 rows x 64 B);
+  // lane (r, kh) reads row r, k-chunk 2 q + kh (q = 0, 1), which sits in slot (2 q + kh) ^ ((r >> 2) & 3)
+  const unsigned lds0 = (unsigned)(size_t)(g256_lds*)smem256 + r * 64;
+  const unsigned wbase = lds0 + (4 * wn) * 2048, abase = lds0 + G256_PART + (4 * wm) * 2048;
+  unsigned qoff[2];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) qoff[q] = (unsigned)(((2 * q + kh) ^ ((r >> 1) & 7)) * 16);
+  for (int q = 0; q < 2; ++q) qoff[q] = (unsigned)(((2 * q + kh) ^ ((r >> 2) & 3)) * 16);
 
+  bf16x8 fw[2][4], fa[2][4];
+  // one operand read of stage s: i < 4 weight tile i, else activation tile i - 4, k16 index q, into register set q
+  auto read1 = [&](int s, int q, int i) {
+    const unsigned so = (s & 3) * G256_STAGE;
+    if (i < 4)
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fw[q][i & 3]) : "v"(wbase + so + qoff[q]), "i"((i & 3) * 2048));
+    else
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[q][i & 3]) : "v"(abase + so + qoff[q]), "i"((i & 3) * 2048));
+  };
+  auto wait_reads = [&](int q) {      // every register written by the reads of set q passes through this wait
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(fw[q][0]), "+v"(fw[q][1]), "+v"(fw[q][2]), "+v"(fw[q][3]), "+v"(fa[q][0]), "+v"(fa[q][1]),
+                   "+v"(fa[q][2]), "+v"(fa[q][3]));
+  };
+  // wait until this wave's pieces of stage s have landed (pieces issued later may stay in flight: 8 per stage, loads
+  // return in order), then the barrier: every wave's pieces of stage s are in LDS, and nobody reads stage s - 2 or
+  // older any more
+  auto stage_ready = [&](int later_stages) {
+    if (later_stages >= 2) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+    else if (later_stages == 1) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+
+  // prologue: stages 0, 1, 2 on their way; stage 0 landed; its first operands read
 #pragma unroll
-  for (int i = 0; i < 16; ++i) piece(0, i);
-  for (int s = 0; s < nk; ++s) {
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    const bool more = s + 1 < nk;
-    const unsigned so = (s & 1) * G256_STAGE;
-    bf16x8 fw[2][4], fa[2][4];
-    // one operand read: i < 4 weight tile i, else activation tile i - 4, k16 index q, into register set b
-    auto read1 = [&](int q, int b, int i) {
-      if (i < 4)
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fw[b][i & 3]) : "v"(wbase + so + qoff[q]), "i"((i & 3) * 4096));
-      else
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[b][i & 3]) : "v"(abase + so + qoff[q]), "i"((i & 3) * 4096));
-    };
+  for (int st = 0; st < 3; ++st)
+    if (st < nk) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) read1(0, 0, i);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int b = q & 1;
-      // every register written by the reads of step q passes through this wait before its first use
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(fw[b][0]), "+v"(fw[b][1]), "+v"(fw[b][2]), "+v"(fw[b][3]), "+v"(fa[b][0]), "+v"(fa[b][1]),
-                     "+v"(fa[b][2]), "+v"(fa[b][3]));
-      // One wave per SIMD issues in order: whatever is not placed between two MFMAs adds to the step instead of
-      // running in the 24 cycles an MFMA leaves free. So the next step's eight operand reads follow the first eight
-      // MFMAs one by one, and four of the next stage's 16 pieces follow every second MFMA of the other eight (the
-      // stage's buffer was last read before this step's barrier).
-#pragma unroll
-      for (int jn = 0; jn < 4; ++jn)
-#pragma unroll
-        for (int jm = 0; jm < 4; ++jm) {
-          const int i = 4 * jn + jm;
-          acc[jn][jm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[b][jn], fa[b][jm], acc[jn][jm], 0, 0, 0);
-          if (i < 8 && q + 1 < 4) read1(q + 1, b ^ 1, i);
-          if (i >= 8 && (i & 1) && more) piece(s + 1, 4 * q + ((i - 8) >> 1));
-          __builtin_amdgcn_sched_barrier(0);
-        }
+      for (int i = 0; i < 8; ++i) piece(st, i);
     }
+  stage_ready(min(nk - 1, 2));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) read1(0, 0, i);
+
+  // Step s: MFMAs of k16 index 0 with the reads of index 1 between them; then stage s + 1 must have landed (barrier in
+  // the MIDDLE of the step, so that its first reads can go out between the MFMAs of index 1 and no step begins with
+  // an exposed LDS latency); then the MFMAs of index 1 with those reads and the pieces of stage s + 3 between them
+  // (its buffer held stage s - 1, which every wave has left behind when it reaches this step's barrier).
+  // One wave per SIMD issues in order: whatever is not placed between two MFMAs adds to the step.
+  for (int s = 0; s < nk; ++s) {
+    wait_reads(0);
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+      for (int jm = 0; jm < 4; ++jm) {
+        const int i = 4 * jn + jm;
+        acc[jn][jm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[0][jn], fa[0][jm], acc[jn][jm], 0, 0, 0);
+        if (i < 8) read1(s, 1, i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    const bool next = s + 1 < nk, issue = s + 3 < nk;
+    if (next) stage_ready(min(nk - 2 - s, 1));      // stage s + 2 (if any) may still be in flight
+    wait_reads(1);
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+      for (int jm = 0; jm < 4; ++jm) {
+        const int i = 4 * jn + jm;
+        acc[jn][jm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[1][jn], fa[1][jm], acc[jn][jm], 0, 0, 0);
+        if (i < 8 && next) read1(s + 1, 0, i);
+        if (i >= 8 && issue) piece(s + 3, i - 8);
+        __builtin_amdgcn_sched_barrier(0);
+      }
   }
 
   // ---- epilogue: tile (jn, jm): lane holds row m = m0 + 128 wm + 32 jm + r, columns nb .. nb + 15
@@ -529,8 +558,8 @@ int launch(const GemmArgs& a, hipStream_t s) {
   void* tok = bd_prof_on() ? bd_prof_begin(s) : nullptr;
   if (use_gemm256(a)) {
     const long long nt = (((long long)a.M + 255) / 256) * (a.Npad / 256);
-    BD_SET_MAX_LDS((gemm256_kernel<EPI, DROP>), 2 * G256_STAGE);
-    hipLaunchKernelGGL((gemm256_kernel<EPI, DROP>), dim3((unsigned)nt), dim3(256), 2 * G256_STAGE, s, a);
+    BD_SET_MAX_LDS((gemm256_kernel<EPI, DROP>), 4 * G256_STAGE);
+    hipLaunchKernelGGL((gemm256_kernel<EPI, DROP>), dim3((unsigned)nt), dim3(256), 4 * G256_STAGE, s, a);
   } else {
     hipLaunchKernelGGL((gemm_bf16_kernel<EPI, DROP>), dim3(persistent_grid(a.n_tiles)), dim3(256), 0, s, a);
   }
