@@ -749,8 +749,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const unsigned sho
 
   for (int qt0 = 0; qt0 < L; qt0 += AT) {
     if (qt0 > 0) __syncthreads();
-    stage_rows<DH>(Qs, qkv + tb * row3 + (size_t)h * DH, row3, qt0, L, tid);
-    stage_rows<DH>(Ds, dO + tb * d + (size_t)h * DH, (size_t)d, qt0, L, tid);
+    // 32-query groups past the end of the sequence have P = 0 and dS = 0: not staged, not multiplied
+    const int ngrp = min(4, (L - qt0 + 31) >> 5);
+    const unsigned qgroups = (1u << ngrp) - 1u;
+    stage_rows<DH>(Qs, qkv + tb * row3 + (size_t)h * DH, row3, qt0, L, tid, qgroups);
+    stage_rows<DH>(Ds, dO + tb * d + (size_t)h * DH, (size_t)d, qt0, L, tid, qgroups);
     if (tid < AT) {
       const int q = qt0 + tid;
       Lq[tid] = q < L ? lse[((size_t)b * H + h) * Ls + q] : INFINITY;
@@ -758,8 +761,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const unsigned sho
     }
     __syncthreads();
     if (!wave_live) continue;
-    // 32-query groups past the end of the sequence have P = 0 and dS = 0: not multiplied
-    const int ngrp = min(4, (L - qt0 + 31) >> 5);
     // Keep decisions of the lane's key against this lane's 32 queries of the tile (bit i <-> query 8 g + 32 (i >> 3) +
     // (i & 7)). One Philox block per query holds the decisions of eight neighbouring KEYS, and the eight lanes that
     // own those keys (same g, same c >> 3) need the same 32 blocks: each evaluates four of them, reduces every block
