@@ -358,6 +358,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
 //    its vector memory path: 2.6 k cycles against 2.0 k of MFMAs, so the stream, not the issue order, sets the pace;
 //    the tile order above keeps the stream in L2 (worth 8 %), the deeper ring is worth 1-6 %. K = 8192 also pays for
 //    its power-of-two row stride (all rows of a piece in one memory channel): K = 8320 runs at 1.18 PFLOP/s, 1.05 at 8192.
+//  * One tile per workgroup. A persistent form that sends the next tile's first stages off before the epilogue was 7 %
+//    slower at K = 1024: loads and stores share vmcnt and do not keep each other's order, so the next tile's first
+//    wait also waits for the epilogue's stores, and tiles dealt out statically lose the hardware's load balancing.
 // -------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(1))) void g256_glb;
 typedef __attribute__((address_space(3))) void g256_lds;
