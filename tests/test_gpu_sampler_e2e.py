@@ -40,7 +40,8 @@ def replay(records, tb, T, L, temperature, use_constraints, fixed, natural=False
 
 
 @pytest.mark.parametrize("variant,kw", [("smiles", {}), ("smiles", {"lengths": True}), ("selfies", {}),
-                                        ("selfies", {"natural": True}), ("group", {})])
+                                        ("selfies", {"natural": True}), ("group", {}),
+                                        ("bpe", {}), ("bpe", {"lengths": True})])   # V = 803: chosen-row workspace
 def test_sampler_end_to_end_replayed_by_oracle(gpu_device, variant, kw):
     T, B, L = 16, 24, 40
     smp0, tok = H.make_sampler(variant)
@@ -60,14 +61,16 @@ def test_sampler_end_to_end_replayed_by_oracle(gpu_device, variant, kw):
         ids, strings = smp.sample(B, L, show_progress=False, seq_offset=7)
     rec = smp._core.record
     assert len(rec) == T and rec[-1]["mode"] == "logits" and rec[0]["mode"] == "hidden"
-    fixed = (rec[0]["ids_before"].numpy() != tb.mask_id).astype(np.uint8) if variant == "smiles" else None
+    fixed = (rec[0]["ids_before"].numpy() != tb.mask_id).astype(np.uint8) if variant in ("smiles", "bpe") else None
     natural = bool(kw.get("natural"))
+    assert (smp._core.row_workspace is None) and ((tok.vocab_size > 128) == (variant in ("group", "bpe")))
     o, r = replay(rec, tb, T, rec[0]["ids_before"].shape[1], 0.9, True, fixed, natural)
     # post-loop repairs on the oracle side
     of = ora.sample_fixup(tb, o["ids"], o["logits"], natural_eos=natural, attn=o["attn"], has_eos=o["has_eos"])
     np.testing.assert_array_equal(ids.cpu().numpy(), of["ids"])
     out = ids.cpu().numpy()
     assert ids.dtype == torch.long and ids.is_cuda and len(strings) == B
+    assert strings == tok.batch_decode(out.tolist(), skip_special_tokens=True)      # decoded on the device
     assert (out != tok.mask_token_id).all()
     cid = tb.count_id
     if variant != "group" and not kw.get("lengths") and not natural:   # very short rows cannot hold two
