@@ -3,8 +3,10 @@
 Drop-in for the reference's ``src/model/backbone.py`` (``DiffusionBackbone``, :132-377):
 same constructor arguments, sub-module / parameter names (hence the same ``state_dict`` keys
 and checkpoint layout), the same seeded initialisation, and the same public methods. The
-modules below only *hold* parameters; all arithmetic runs in ``libbidiff_hip.so`` through
-``bd_backbone_forward`` (inference) or the training-step kernels (autograd path).
+modules below hold the parameters; ``DiffusionBackbone`` runs the whole stack in ``libbidiff_hip.so`` through
+``bd_backbone_forward`` (inference) or the training-step kernels (autograd path) and never calls the
+block-level modules, whose own ``forward`` (inference only, ``_blocks.py``) serves callers that apply a
+single block or projection.
 """
 import ctypes as C
 from typing import Optional
@@ -18,7 +20,7 @@ from .. import _lib
 
 
 class MultiHeadAttention(nn.Module):
-    """Parameter container: q/k/v/out projections (reference backbone.py:9-30)."""
+    """q/k/v/out projections (reference backbone.py:9-78)."""
 
     def __init__(self, hidden_size: int, num_heads: int, dropout: float = 0.1):
         super().__init__()
@@ -33,9 +35,15 @@ class MultiHeadAttention(nn.Module):
         self.out_proj = nn.Linear(hidden_size, hidden_size)
         self.dropout = nn.Dropout(dropout)
 
+    def forward(self, x: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """out_proj(softmax(q k^T / sqrt(dh) + key padding) v) of x [B, L, d]; attention_mask [B, L], non-zero =
+        visible key; rows whose keys are all padded come out as the output bias (reference backbone.py:32-78)."""
+        from ._blocks import attention_forward
+        return attention_forward(self, x, attention_mask)
+
 
 class FeedForward(nn.Module):
-    """Parameter container: fc1 -> GELU -> fc2 (reference backbone.py:81-93)."""
+    """fc1 -> GELU -> fc2 (reference backbone.py:81-101)."""
 
     def __init__(self, hidden_size: int, ffn_hidden_size: int, dropout: float = 0.1):
         super().__init__()
@@ -43,9 +51,14 @@ class FeedForward(nn.Module):
         self.fc2 = nn.Linear(ffn_hidden_size, hidden_size)
         self.dropout = nn.Dropout(dropout)
 
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """fc2(gelu(fc1(x))) (reference backbone.py:95-101)."""
+        from ._blocks import ffn_forward
+        return ffn_forward(self, x)
+
 
 class TransformerBlock(nn.Module):
-    """Parameter container of one pre-norm block (reference backbone.py:104-118)."""
+    """One pre-norm block (reference backbone.py:104-129)."""
 
     def __init__(self, hidden_size: int, num_heads: int, ffn_hidden_size: int, dropout: float = 0.1):
         super().__init__()
@@ -53,6 +66,11 @@ class TransformerBlock(nn.Module):
         self.attn = MultiHeadAttention(hidden_size, num_heads, dropout)
         self.norm2 = nn.LayerNorm(hidden_size)
         self.ffn = FeedForward(hidden_size, ffn_hidden_size, dropout)
+
+    def forward(self, x: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x + attn(norm1(x)), then + ffn(norm2(.)) (reference backbone.py:120-129)."""
+        from ._blocks import block_forward
+        return block_forward(self, x, attention_mask)
 
 
 class _Packed:

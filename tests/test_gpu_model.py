@@ -197,3 +197,68 @@ def test_forward_process_philox_matches_oracle_at_scale(gpu_device):
     assert torch.equal(n2[~i2], ids2[~i2]) and (n2[i2] == 1).all()
     rate = i2[:, 1:-1].float().mean().item()
     assert abs(rate - float(m.mask_schedule[25])) < 5e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,heads,ffn", [(128, 2, 256), (384, 3, 1536), (256, 8, 512)])
+def test_block_level_modules_are_callable_and_match_the_fp32_restatement(gpu_device, d, heads, ffn):
+    """MultiHeadAttention / FeedForward / TransformerBlock forward on their own (reference backbone.py:32-78,
+    95-101, 120-129): bf16 operands, so 2e-2 of the fp32 restatement; a fully padded sequence gets exactly the
+    output bias from the attention; stacking the blocks reproduces the backbone's hidden states."""
+    import torch.nn.functional as F
+    dev = gpu_device
+    torch.manual_seed(5)
+    bb = DiffusionBackbone(39, d, 2, heads, ffn, 64, 10, 0.1, 0)
+    RI.perturb_state_dict(bb.state_dict(), 9)
+    sd = {k: v.clone() for k, v in bb.state_dict().items()}
+    bb = bb.to(dev).eval()
+    B, L = 5, 37
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, L, d, generator=g)
+    mask = torch.ones(B, L, dtype=torch.long)
+    mask[1, 20:] = 0
+    mask[3, :] = 0                                             # fully padded
+    blk = bb.layers[0]
+    rel = lambda a, b: ((a.cpu() - b).abs().max() / b.abs().max()).item()
+    with torch.no_grad():
+        att = blk.attn(x.to(dev), mask.to(dev))
+        att_ref = BR.attention(x, sd, "layers.0.attn", heads, mask)
+        assert att.shape == (B, L, d) and att.dtype == torch.float32
+        assert rel(att, att_ref) < 2e-2
+        assert torch.allclose(att[3].cpu(), sd["layers.0.attn.out_proj.bias"].expand(L, d), atol=1e-6)
+        assert rel(blk.attn(x.to(dev)), BR.attention(x, sd, "layers.0.attn", heads, None)) < 2e-2
+        ff = blk.ffn(x.to(dev))
+        ff_ref = F.linear(F.gelu(F.linear(x, sd["layers.0.ffn.fc1.weight"], sd["layers.0.ffn.fc1.bias"])),
+                          sd["layers.0.ffn.fc2.weight"], sd["layers.0.ffn.fc2.bias"])
+        assert rel(ff, ff_ref) < 2e-2
+        y = blk(x.to(dev), mask.to(dev))
+        h = F.layer_norm(x, (d,), sd["layers.0.norm1.weight"], sd["layers.0.norm1.bias"], 1e-5)
+        y_ref = x + BR.attention(h, sd, "layers.0.attn", heads, mask)
+        h = F.layer_norm(y_ref, (d,), sd["layers.0.norm2.weight"], sd["layers.0.norm2.bias"], 1e-5)
+        y_ref = y_ref + F.linear(F.gelu(F.linear(h, sd["layers.0.ffn.fc1.weight"], sd["layers.0.ffn.fc1.bias"])),
+                                 sd["layers.0.ffn.fc2.weight"], sd["layers.0.ffn.fc2.bias"])
+        assert rel(y, y_ref) < 2e-2
+        assert torch.equal(x, x.clone()) and y.data_ptr() != x.data_ptr()
+        # the blocks one after another on the embedded input = the backbone's hidden states after the last block
+        ids = torch.randint(5, 39, (B, L), generator=g)
+        t = torch.randint(1, 11, (B,), generator=g)
+        pos = torch.arange(L)
+        emb = sd["token_embedding.weight"][ids] + sd["position_embedding.weight"][pos][None] + sd["timestep_embedding.weight"][t][:, None]
+        z = emb.to(dev)
+        for layer in bb.layers:
+            z = layer(z, mask.to(dev))
+        want = bb.get_hidden_states(ids.to(dev), t.to(dev), mask.to(dev), layer_idx=len(bb.layers) - 1)
+        live = mask.bool()
+        assert ((z.cpu() - want.cpu()).abs()[live].max() / want.cpu().abs()[live].max()).item() < 2e-2
+    # a parameter update is picked up (the bf16 copies are rebuilt)
+    with torch.no_grad():
+        before = blk.ffn(x.to(dev)).clone()
+        blk.ffn.fc2.bias.add_(1.0)
+        after = blk.ffn(x.to(dev))
+        assert torch.allclose(after, before + 1.0, atol=1e-5)
+    # inference only: under autograd with trainable parameters the stand-alone forward refuses
+    with pytest.raises(NotImplementedError, match="inference-only"):
+        blk(x.to(dev), mask.to(dev))
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        with torch.no_grad():
+            blk(x, mask)
