@@ -64,7 +64,8 @@ class Dropout(C.Structure):
 
 class CastJob(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("ld", C.c_int),
-                ("transpose", C.c_int)]
+                ("transpose", C.c_int), ("pad_axis", C.c_int), ("group", C.c_int), ("group_pad", C.c_int),
+                ("scale", C.c_float)]
 
 
 class StepArgs(C.Structure):
@@ -152,6 +153,7 @@ SIGNATURES = {
     "bd_muon_step_guarded": (C.c_int, [VP, VP, VP, VP, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
                                        C.c_int, C.c_int, VP, C.c_float, VP]),
     "bd_multi_cast_bf16": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP]),
+    "bd_multi_unpad_add_f32": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP]),
     "bd_cast_f32_to_bf16": (C.c_int, [VP, VP, C.c_longlong, VP]),
     "bd_gemm_panel_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "bd_gemm_panel": (C.c_int, [VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, VP]),

@@ -173,12 +173,14 @@ class RowPacking:
 
 
 class _TrainWeights:
-    """bf16 copies (and transposes for the data-gradient GEMMs) of the current parameters. Head sizes
-    the attention kernels do not have (e.g. 48) are zero-padded to 32 / 64 / 128 (``dhp``); the q rows
-    absorb sqrt(dhp / dh) because the kernels scale by 1 / sqrt(dhp).
+    """bf16 copies (and transposes for the data-gradient GEMMs) of the current parameters in persistent buffers
+    that ONE launch (bd_multi_cast_bf16 over a job table of all matrices) refreshes after each optimizer step.
 
-    Without head padding the copies live in persistent buffers that ONE launch (bd_multi_cast_bf16
-    over a job table of all matrices) refreshes after each optimizer step."""
+    Head sizes the attention kernels do not tile (e.g. 48) run zero-padded to 32 / 64 / 128 (``dhp``): the copies of
+    the q / k / v projections have their rows, the copy of the output projection its columns, re-blocked head by head
+    by the same job table (the padding entries are zeroed once and never written); the q rows absorb
+    sqrt(dhp / dh) because the kernels scale by 1 / sqrt(dhp). Their weight gradients are accumulated in padded
+    fp32 buffers (``pad_grads``) and added to the parameters' gradients by one bd_multi_unpad_add_f32 launch."""
 
     def __init__(self, model):
         d, V, H = model.hidden_size, model.vocab_size, model.num_heads
@@ -193,42 +195,70 @@ class _TrainWeights:
         self.qfix = (dhp / dh) ** 0.5
         self.vpad = (V + 127) // 128 * 128
         self.ptr_key = tuple(p.data_ptr() for p in model._params())
-        self.jobs = None
-        if dhp == dh:
-            self._build_persistent(model)
-        else:
-            self._build_padded(model)
+        self.padded = dhp != dh
+        self._build(model)
 
-    def _build_persistent(self, model):
-        d, F, V = model.hidden_size, model.ffn_hidden_size, model.vocab_size
+    def _build(self, model):
+        d, F, V, aw = model.hidden_size, model.ffn_hidden_size, model.vocab_size, self.aw
+        dh, dhp, padded = self.dh, self.dhp, self.padded
         dev = model.output_proj.weight.device
         bf = torch.bfloat16
         jobs = []
 
-        def job(src, dst, ld, mode, row_off=0, col_off=0):
+        def job(src, dst, ld, mode, row_off=0, col_off=0, pad_axis=0, scale=1.0):
             rows, cols = (src.shape if src.dim() == 2 else (1, src.shape[0]))
             esz = 4 if mode == 2 else 2
-            jobs.append(_lib.CastJob(src.data_ptr(), dst.data_ptr() + esz * (row_off * ld + col_off), rows, cols, ld, mode))
+            if not padded:
+                pad_axis = 0
+            jobs.append(_lib.CastJob(src.data_ptr(), dst.data_ptr() + esz * (row_off * ld + col_off), rows, cols, ld, mode,
+                                     pad_axis, dh, dhp, float(scale)))
 
+        new = torch.zeros if padded else torch.empty          # padding entries stay zero
         self.layers = []
+        n_l = len(model.layers)
+        # padded fp32 accumulators of the attention projections' weight gradients, one flat buffer zeroed per backward
+        self.pad_grads = torch.zeros(n_l * (3 * aw * d + 3 * aw + d * aw), device=dev) if padded else None
+        self.pad_views, unpad = [], []
+
+        def unjob(src, dst_param, ld, pad_axis, scale):
+            rows, cols = (dst_param.shape if dst_param.dim() == 2 else (1, dst_param.shape[0]))
+            unpad.append((src, dst_param, rows, cols, ld, pad_axis, float(scale)))
+
+        off = 0
         for blk in model.layers:
             a = blk.attn
-            w = {"wqkv": torch.empty(3 * d, d, dtype=bf, device=dev), "wqkvT": torch.empty(d, 3 * d, dtype=bf, device=dev),
-                 "bqkv": torch.empty(3 * d, device=dev),
-                 "wo": torch.empty(d, d, dtype=bf, device=dev), "woT": torch.empty(d, d, dtype=bf, device=dev),
+            w = {"wqkv": new(3 * aw, d, dtype=bf, device=dev), "wqkvT": new(d, 3 * aw, dtype=bf, device=dev),
+                 "bqkv": new(3 * aw, device=dev),
+                 "wo": new(d, aw, dtype=bf, device=dev), "woT": new(aw, d, dtype=bf, device=dev),
                  "w1": torch.empty(F, d, dtype=bf, device=dev), "w1T": torch.empty(d, F, dtype=bf, device=dev),
                  "w2": torch.empty(d, F, dtype=bf, device=dev), "w2T": torch.empty(F, d, dtype=bf, device=dev)}
             for i, pr in enumerate((a.q_proj, a.k_proj, a.v_proj)):
-                job(pr.weight, w["wqkv"], d, 0, row_off=i * d)
-                job(pr.weight, w["wqkvT"], 3 * d, 1, col_off=i * d)
-                job(pr.bias, w["bqkv"], 3 * d, 2, col_off=i * d)
-            job(a.out_proj.weight, w["wo"], d, 0)
-            job(a.out_proj.weight, w["woT"], d, 1)
+                f = self.qfix if i == 0 else 1.0
+                job(pr.weight, w["wqkv"], d, 0, row_off=i * aw, pad_axis=1, scale=f)
+                job(pr.weight, w["wqkvT"], 3 * aw, 1, col_off=i * aw, pad_axis=1, scale=f)
+                job(pr.bias, w["bqkv"], 3 * aw, 2, col_off=i * aw, pad_axis=2, scale=f)
+            job(a.out_proj.weight, w["wo"], aw, 0, pad_axis=2)
+            job(a.out_proj.weight, w["woT"], d, 1, pad_axis=2)
             job(blk.ffn.fc1.weight, w["w1"], d, 0)
             job(blk.ffn.fc1.weight, w["w1T"], F, 1)
             job(blk.ffn.fc2.weight, w["w2"], F, 0)
             job(blk.ffn.fc2.weight, w["w2T"], d, 1)
             self.layers.append(w)
+            if padded:
+                g = self.pad_grads
+                gw = [g[off + i * aw * d: off + (i + 1) * aw * d].view(aw, d) for i in range(3)]
+                off += 3 * aw * d
+                gb = [g[off + i * aw: off + (i + 1) * aw] for i in range(3)]
+                off += 3 * aw
+                go = g[off: off + d * aw].view(d, aw)
+                off += d * aw
+                self.pad_views.append({"w": gw, "b": gb, "o": go})
+                for i, pr in enumerate((a.q_proj, a.k_proj, a.v_proj)):
+                    f = self.qfix if i == 0 else 1.0
+                    unjob(gw[i], pr.weight, d, 1, f)
+                    unjob(gb[i], pr.bias, aw, 2, f)
+                unjob(go, a.out_proj.weight, aw, 2, 1.0)
+        self.unpad = unpad
         self.wout = torch.zeros(self.vpad, d, dtype=bf, device=dev)          # rows past V stay zero
         self.woutT = torch.zeros(d, self.vpad, dtype=bf, device=dev)
         job(model.output_proj.weight, self.wout, d, 0)
@@ -238,43 +268,27 @@ class _TrainWeights:
         self.n_jobs = len(jobs)
         self.max_rows = max(j.rows for j in jobs)
         self.max_cols = max(j.cols for j in jobs)
+        self._unpad_key, self._unpad_jobs = None, None
         self.refresh(model)
 
     def refresh(self, model):
-        if self.jobs is None:
-            self._build_padded(model)
-            return
         _ck(_lib.lib().bd_multi_cast_bf16(_lib.ptr(self.jobs), self.n_jobs, self.max_rows, self.max_cols, _s()),
             "bd_multi_cast_bf16")
 
-    def _build_padded(self, model):
-        d, V, H = model.hidden_size, model.vocab_size, model.num_heads
-        bf = torch.bfloat16
-        dh, dhp, aw, qfix = self.dh, self.dhp, self.aw, self.qfix
-
-        def pad_rows(w):       # [H*dh, ...] -> [H*dhp, ...]
-            out = w.new_zeros((H, dhp) + tuple(w.shape[1:]))
-            out[:, :dh] = w.view((H, dh) + tuple(w.shape[1:]))
-            return out.view((aw,) + tuple(w.shape[1:]))
-
-        self.layers = []
-        with torch.no_grad():
-            for blk in model.layers:
-                a = blk.attn
-                wqkv = torch.cat([pad_rows(a.q_proj.weight * qfix), pad_rows(a.k_proj.weight), pad_rows(a.v_proj.weight)], 0)
-                bqkv = torch.cat([pad_rows(a.q_proj.bias * qfix), pad_rows(a.k_proj.bias), pad_rows(a.v_proj.bias)], 0)
-                wo = pad_rows(a.out_proj.weight.t().contiguous()).t()
-                self.layers.append({
-                    "wqkv": wqkv.to(bf).contiguous(), "wqkvT": wqkv.t().to(bf).contiguous(),
-                    "bqkv": bqkv.float().contiguous(),
-                    "wo": wo.to(bf).contiguous(), "woT": wo.t().to(bf).contiguous(),
-                    "w1": blk.ffn.fc1.weight.to(bf).contiguous(), "w1T": blk.ffn.fc1.weight.t().to(bf).contiguous(),
-                    "w2": blk.ffn.fc2.weight.to(bf).contiguous(), "w2T": blk.ffn.fc2.weight.t().to(bf).contiguous(),
-                })
-            wout = torch.zeros(self.vpad, d, dtype=bf, device=model.output_proj.weight.device)
-            wout[:V] = model.output_proj.weight.to(bf)
-            self.wout = wout
-            self.woutT = wout.t().contiguous()
+    def unpad_gradients(self, gbuf):
+        """pad_grads -> the parameters' gradient buffers (``gbuf(param)``), one launch. The job table is rebuilt only
+        when a destination moved (gradients bound to the optimizer's flat buffer keep their addresses)."""
+        dsts = [gbuf(p) for _, p, *_ in self.unpad]
+        key = tuple(t.data_ptr() for t in dsts)
+        if key != self._unpad_key:
+            jobs = [_lib.CastJob(src.data_ptr(), dst.data_ptr(), rows, cols, ld, 0, pad_axis, self.dh, self.dhp, scale)
+                    for (src, _, rows, cols, ld, pad_axis, scale), dst in zip(self.unpad, dsts)]
+            arr = (_lib.CastJob * len(jobs))(*jobs)
+            self._unpad_jobs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.pad_grads.device)
+            self._unpad_key = key
+            self._unpad_dims = (len(jobs), max(j.rows for j in jobs), max(j.cols for j in jobs))
+        n, mr, mc = self._unpad_dims
+        _ck(_lib.lib().bd_multi_unpad_add_f32(_lib.ptr(self._unpad_jobs), n, mr, mc, _s()), "bd_multi_unpad_add_f32")
 
 
 def _train_weights(model):
@@ -437,7 +451,9 @@ class _BackboneFn(torch.autograd.Function):
         # writes for the next one), and a layer begins by waiting for the hand-over of two layers before: one wait
         # of the main stream. The last layer hands over launch by launch so that no tail is left behind it.
         main = torch.cuda.current_stream(dev)
-        side = None if padded else _side_stream(dev)
+        side = _side_stream(dev)
+        if padded:
+            tw.pad_grads.zero_()
         main_h = _STREAM[0]
         side_h = C.c_void_p(side.cuda_stream) if side is not None else None
         nb = 2 if side is not None else 1
@@ -504,12 +520,9 @@ class _BackboneFn(torch.autograd.Function):
             _ln_bwd(dh_buf, s["x_mid"], s["st2"], blk.norm2.weight, dx, dx, gbuf(blk.norm2.weight), gbuf(blk.norm2.bias), M, d,
                     dx_bf16=dy2)
             # x_mid = x_in + out_proj(attention(qkv(LN1(x_in))))
-            if not padded:
-                wgrad_side(li, dy2, s["att"], gbuf(a.out_proj.weight), d, d, gbuf(a.out_proj.bias))
-            else:       # gradient of the zero-padded weight, real columns added to the parameter's
-                tmp = zeros(d, aw)
-                _wgrad(dy2, s["att"], tmp, M, d, aw, db=gbuf(a.out_proj.bias))
-                gbuf(a.out_proj.weight).view(d, H, dh).add_(tmp.view(d, H, dhp)[:, :, :dh])
+            # (zero-padded heads: the padded copies' gradients go to tw.pad_grads and are added to the parameters' at the end)
+            wgrad_side(li, dy2, s["att"], tw.pad_views[li]["o"] if padded else gbuf(a.out_proj.weight), d, aw,
+                       gbuf(a.out_proj.bias))
             _gemm(dy2, w["woT"], None, datt, M, aw, aw, d, aw, 0)
             if pk is None:
                 _ck(lib.bd_attention_bwd_drop(_lib.ptr(s["qkv"]), _lib.ptr(keymask), _lib.ptr(s["att"]), _lib.ptr(datt),
@@ -522,13 +535,8 @@ class _BackboneFn(torch.autograd.Function):
             projs = (a.q_proj, a.k_proj, a.v_proj)
             if not padded:      # the three row segments of the stacked gradient, one launch
                 wgrad_side(li, dqkv, s["h1"], [gbuf(pr.weight) for pr in projs], 3 * aw, d, [gbuf(pr.bias) for pr in projs])
-            else:   # rows of the padded projections; the q rows were scaled by qfix in the forward
-                tw_, tb_ = zeros(3, aw, d), zeros(3, aw)
-                _wgrad(dqkv, s["h1"], [tw_[0], tw_[1], tw_[2]], M, 3 * aw, d, db=[tb_[0], tb_[1], tb_[2]])
-                for i, proj in enumerate(projs):
-                    f = tw.qfix if i == 0 else 1.0
-                    gbuf(proj.weight).view(H, dh, d).add_(tw_[i].view(H, dhp, d)[:, :dh], alpha=f)
-                    gbuf(proj.bias).view(H, dh).add_(tb_[i].view(H, dhp)[:, :dh], alpha=f)
+            else:   # rows of the padded projections (the q rows were scaled by qfix in the forward: undone when un-padding)
+                wgrad_side(li, dqkv, s["h1"], tw.pad_views[li]["w"], 3 * aw, d, tw.pad_views[li]["b"])
             _gemm(dqkv, w["wqkvT"], None, dh_buf, M, d, d, 3 * aw, d, 0)
             _ln_bwd(dh_buf, s["x_in"], s["st1"], blk.norm1.weight, dx, dx, gbuf(blk.norm1.weight), gbuf(blk.norm1.bias), M, d,
                     dx_bf16=dy_next if li > stop_layer else None, drop=drop, site=max(0, 4 * (li - 1) + 3))
@@ -553,6 +561,8 @@ class _BackboneFn(torch.autograd.Function):
                                         model.num_diffusion_steps + 1, _s()), "bd_embed_bwd_varlen")
         if side is not None:
             main.wait_stream(side)       # every gradient is complete before autograd / the optimizer go on
+        if padded:
+            tw.unpad_gradients(gbuf)
         out = [None, None, None, None, None, None]
         for p in params:
             g = grads.get(p)

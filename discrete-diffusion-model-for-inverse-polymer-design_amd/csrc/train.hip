@@ -1091,6 +1091,8 @@ __global__ void guard_update_kernel(int* __restrict__ guard, const float* __rest
 // training GEMMs read, refreshed after every optimizer step): job j copies src [rows, cols] to
 // dst[r * ld + c], or transposed to dst[c * ld + r]. 64 x 64 tiles through LDS; gridDim.y = jobs,
 // gridDim.x = tiles of the largest job (workgroups past a job's tile count leave).
+__device__ __forceinline__ int cast_job_reblock(const bd_cast_job& j, int i) { return (i / j.group) * j.group_pad + i % j.group; }
+
 __global__ __launch_bounds__(256) void multi_cast_kernel(const bd_cast_job* __restrict__ jobs) {
   __shared__ float tile[64][65];
   const bd_cast_job j = jobs[blockIdx.y];
@@ -1099,24 +1101,48 @@ __global__ __launch_bounds__(256) void multi_cast_kernel(const bd_cast_job* __re
   const int r0 = (blockIdx.x / tc) * 64, c0 = (blockIdx.x % tc) * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   unsigned short* dst = (unsigned short*)j.dst;
+  const float sc = j.pad_axis ? j.scale : 1.0f;
+  // destination indices of source row r / source column c (head re-blocking moves one of them)
+  auto drow = [&](int r) { return j.pad_axis == 1 ? cast_job_reblock(j, r) : r; };
+  auto dcol = [&](int c) { return j.pad_axis == 2 ? cast_job_reblock(j, c) : c; };
   if (j.transpose & 2) {        // plain fp32 copy (stacked biases)
     if (c0 + tx < j.cols)
       for (int i = ty; i < 64 && r0 + i < j.rows; i += 4)
-        ((float*)j.dst)[(size_t)(r0 + i) * j.ld + c0 + tx] = j.src[(size_t)(r0 + i) * j.cols + c0 + tx];
+        ((float*)j.dst)[(size_t)drow(r0 + i) * j.ld + dcol(c0 + tx)] = sc * j.src[(size_t)(r0 + i) * j.cols + c0 + tx];
     return;
   }
   if (!j.transpose) {
     if (c0 + tx < j.cols)
       for (int i = ty; i < 64 && r0 + i < j.rows; i += 4)
-        dst[(size_t)(r0 + i) * j.ld + c0 + tx] = bd_f32_to_bf16(j.src[(size_t)(r0 + i) * j.cols + c0 + tx]);
+        dst[(size_t)drow(r0 + i) * j.ld + dcol(c0 + tx)] = bd_f32_to_bf16(sc * j.src[(size_t)(r0 + i) * j.cols + c0 + tx]);
     return;
   }
   for (int i = ty; i < 64; i += 4)
-    tile[i][tx] = (r0 + i < j.rows && c0 + tx < j.cols) ? j.src[(size_t)(r0 + i) * j.cols + c0 + tx] : 0.f;
+    tile[i][tx] = (r0 + i < j.rows && c0 + tx < j.cols) ? sc * j.src[(size_t)(r0 + i) * j.cols + c0 + tx] : 0.f;
   __syncthreads();
   if (r0 + tx < j.rows)
     for (int i = ty; i < 64 && c0 + i < j.cols; i += 4)
-      dst[(size_t)(c0 + i) * j.ld + r0 + tx] = bd_f32_to_bf16(tile[tx][i]);
+      dst[(size_t)dcol(c0 + i) * j.ld + drow(r0 + tx)] = bd_f32_to_bf16(tile[tx][i]);
+}
+
+// dst [rows, cols] += scale * src at the re-blocked index (gradients of zero-padded weight copies back to the
+// parameters' own shapes); every destination element belongs to one thread of one job
+__global__ __launch_bounds__(256) void multi_unpad_add_kernel(const bd_cast_job* __restrict__ jobs) {
+  const bd_cast_job j = jobs[blockIdx.y];
+  const int tc = (j.cols + 63) / 64, tr = (j.rows + 63) / 64;
+  if ((int)blockIdx.x >= tc * tr) return;
+  const int r0 = (blockIdx.x / tc) * 64, c0 = (blockIdx.x % tc) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const float sc = (j.pad_axis == 0 && j.scale == 0.f) ? 1.0f : j.scale;
+  float* dst = (float*)j.dst;
+  const int c = c0 + tx;
+  if (c >= j.cols) return;
+  const int pc = j.pad_axis == 2 ? cast_job_reblock(j, c) : c;
+  for (int i = ty; i < 64 && r0 + i < j.rows; i += 4) {
+    const int r = r0 + i;
+    const int pr = j.pad_axis == 1 ? cast_job_reblock(j, r) : r;
+    dst[(size_t)r * j.cols + c] += sc * j.src[(size_t)pr * j.ld + pc];
+  }
 }
 
 // x bf16 <- fp32 (flat), used to refresh the bf16 weight copies after an optimizer step
@@ -1540,6 +1566,15 @@ static int muon_step_impl(float* params, const float* grads, float* momentum_buf
   hipLaunchKernelGGL(muon_apply_kernel, dim3(gx, nb), dim3(256), 0, s, params, X, decay, (float)(-(double)lr * (double)scale),
                      rows, cols, guarded ? grad_sumsq : (const float*)nullptr);
   return bd_check_launch("bd_muon_step");
+}
+
+extern "C" int bd_multi_unpad_add_f32(const bd_cast_job* jobs_device, int n_jobs, int max_rows, int max_cols, void* stream) {
+  BD_REQUIRE(jobs_device && n_jobs > 0 && n_jobs <= 65535 && max_rows > 0 && max_cols > 0, "bd_multi_unpad_add_f32: bad argument");
+  const long long tiles = (long long)((max_rows + 63) / 64) * ((max_cols + 63) / 64);
+  BD_REQUIRE(tiles < (1ll << 31), "bd_multi_unpad_add_f32: job too large");
+  bd_prof_scope prof(stream, 0.0, BD_PROF_OPT);
+  hipLaunchKernelGGL(multi_unpad_add_kernel, dim3((unsigned)tiles, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_device);
+  return bd_check_launch("bd_multi_unpad_add_f32");
 }
 
 extern "C" int bd_multi_cast_bf16(const bd_cast_job* jobs_device, int n_jobs, int max_rows, int max_cols, void* stream) {

@@ -446,13 +446,24 @@ int bd_muon_step_guarded(float* params, const float* grads, float* momentum_buf,
  * or, with transpose == 1, to dst[c * ld + r]; transpose == 2 copies fp32 to fp32 dst[r * ld + c] (stacked
  * biases). jobs_device is a device array; max_rows / max_cols bound
  * every job's shape. (The bf16 weight copies autocast makes per GEMM in the reference's training step,
- * trainer_backbone.py:434-436, plus the transposes the data-gradient GEMMs read.) */
+ * trainer_backbone.py:434-436, plus the transposes the data-gradient GEMMs read.)
+ * Head re-blocking (heads whose size the attention kernels do not tile, e.g. 48, run zero-padded to 64): with
+ * pad_axis == 1 the source ROW index r, with pad_axis == 2 the source COLUMN index c, is replaced by
+ * (i / group) * group_pad + i % group before the store above, and the value is multiplied by scale; the
+ * destination's padding entries are never written (the caller zeroes them once). pad_axis == 0: no re-blocking,
+ * group / group_pad / scale ignored. */
 typedef struct bd_cast_job {
   const float* src;
   void* dst;
   int rows, cols, ld, transpose;
+  int pad_axis, group, group_pad;
+  float scale;
 } bd_cast_job;
 int bd_multi_cast_bf16(const bd_cast_job* jobs_device, int n_jobs, int max_rows, int max_cols, void* stream);
+/* The way back for gradients, fp32 to fp32: dst [rows, cols] (contiguous) += scale * src[r' * ld + c'] with the
+ * re-blocked index r' (pad_axis 1) or c' (pad_axis 2) as above (pad_axis 0, scale 0 is read as 1: a plain add);
+ * transpose is ignored. */
+int bd_multi_unpad_add_f32(const bd_cast_job* jobs_device, int n_jobs, int max_rows, int max_cols, void* stream);
 
 /* y (bf16) = x (fp32), flat. */
 int bd_cast_f32_to_bf16(const float* x, void* y, long long n, void* stream);

@@ -606,6 +606,54 @@ def test_multi_cast_jobs(gpu_device):
     assert torch.equal(bst[768:], bias) and (bst[:768] == 0).all()
 
 
+def test_cast_jobs_reblock_heads_and_unpad_gradients(gpu_device):
+    """Head re-blocking of the cast jobs (8 heads of 48 stored as 8 zero-padded heads of 64, with a scale): rows for the
+    q / k / v projections, columns for the output projection, straight and transposed, and the fp32 bias; then the way
+    back for gradients, bd_multi_unpad_add_f32, which ADDS scale * (the real entries of the padded gradient)."""
+    dev = gpu_device
+    H, dh, dhp, d = 8, 48, 64, 384
+    aw = H * dhp
+    g = torch.Generator().manual_seed(2)
+    wq = torch.randn(H * dh, d, generator=g).to(dev)
+    wo = torch.randn(d, H * dh, generator=g).to(dev)
+    bq = torch.randn(H * dh, generator=g).to(dev)
+    f = (dhp / dh) ** 0.5
+    wq_p = torch.zeros(aw, d, dtype=torch.bfloat16, device=dev); wq_pT = torch.zeros(d, aw, dtype=torch.bfloat16, device=dev)
+    wo_p = torch.zeros(d, aw, dtype=torch.bfloat16, device=dev); wo_pT = torch.zeros(aw, d, dtype=torch.bfloat16, device=dev)
+    bq_p = torch.zeros(aw, device=dev)
+    J = _lib.CastJob
+    jobs = [J(wq.data_ptr(), wq_p.data_ptr(), H * dh, d, d, 0, 1, dh, dhp, f),
+            J(wq.data_ptr(), wq_pT.data_ptr(), H * dh, d, aw, 1, 1, dh, dhp, f),
+            J(wo.data_ptr(), wo_p.data_ptr(), d, H * dh, aw, 0, 2, dh, dhp, 1.0),
+            J(wo.data_ptr(), wo_pT.data_ptr(), d, H * dh, d, 1, 2, dh, dhp, 1.0),
+            J(bq.data_ptr(), bq_p.data_ptr(), 1, H * dh, aw, 2, 2, dh, dhp, f)]
+    arr = (J * len(jobs))(*jobs)
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    _lib.check(_lib.lib().bd_multi_cast_bf16(_lib.ptr(table), len(jobs), 384, 384, _s()), "multi_cast")
+    pad_rows = lambda w: torch.nn.functional.pad(w.view(H, dh, -1), (0, 0, 0, dhp - dh)).reshape(aw, -1)
+    want_q = pad_rows(wq * f).bfloat16()
+    want_o = pad_rows(wo.t().contiguous()).t().bfloat16()
+    assert torch.equal(wq_p, want_q) and torch.equal(wq_pT, want_q.t())
+    assert torch.equal(wo_p, want_o) and torch.equal(wo_pT, want_o.t())
+    assert torch.equal(bq_p, pad_rows((bq * f)[:, None])[:, 0])
+    # gradients back: dst += scale * real entries; the padding entries of the source are ignored
+    gq_p = torch.randn(aw, d, generator=g).to(dev); go_p = torch.randn(d, aw, generator=g).to(dev); gb_p = torch.randn(aw, generator=g).to(dev)
+    gq = torch.ones(H * dh, d, device=dev); go = torch.full((d, H * dh), 2.0, device=dev); gb = torch.zeros(H * dh, device=dev)
+    plain_src = torch.randn(70, 33, generator=g).to(dev); plain_dst = torch.ones(70, 33, device=dev)
+    jobs = [J(gq_p.data_ptr(), gq.data_ptr(), H * dh, d, d, 0, 1, dh, dhp, f),
+            J(go_p.data_ptr(), go.data_ptr(), d, H * dh, aw, 0, 2, dh, dhp, 1.0),
+            J(gb_p.data_ptr(), gb.data_ptr(), 1, H * dh, aw, 0, 2, dh, dhp, f),
+            J(plain_src.data_ptr(), plain_dst.data_ptr(), 70, 33, 33, 0, 0, 0, 0, 0.0)]
+    arr = (J * len(jobs))(*jobs)
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    _lib.check(_lib.lib().bd_multi_unpad_add_f32(_lib.ptr(table), len(jobs), 384, 384, _s()), "unpad")
+    unpad_rows = lambda w: w.view(H, dhp, -1)[:, :dh].reshape(H * dh, -1)
+    assert torch.allclose(gq, 1.0 + f * unpad_rows(gq_p), atol=1e-6)
+    assert torch.allclose(go, 2.0 + unpad_rows(go_p.t().contiguous()).t(), atol=1e-6)
+    assert torch.allclose(gb, f * unpad_rows(gb_p[:, None])[:, 0], atol=1e-6)
+    assert torch.allclose(plain_dst, 1.0 + plain_src, atol=1e-6)
+
+
 def test_training_weight_copies_follow_the_parameters(gpu_device):
     """The persistent bf16 copies are refreshed (one launch) after an optimizer step and equal fresh casts."""
     dev = gpu_device
