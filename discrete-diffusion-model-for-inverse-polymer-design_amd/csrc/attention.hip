@@ -29,6 +29,8 @@ __device__ __forceinline__ int kv_off(int row, int ch) {
   return ROWB * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }
 
+typedef __attribute__((address_space(3))) void attn_lds;
+
 __device__ __forceinline__ s16x4 lds_read_tr(const unsigned char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
       (__attribute__((address_space(3))) s16x4*)(p));
@@ -57,12 +59,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
   constexpr int DT = DH / 16;   // output d-tiles of the second product
   constexpr int CPR = DH / 8;   // 16-byte chunks per K/V row
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, c = lane & 15;
   const int b = blockIdx.z, h = blockIdx.y;
   const int d = H * DH;
   const size_t row3 = (size_t)3 * d;
   const int q0 = blockIdx.x * (64 * QB) + wave * (16 * QB);   // block qb: queries q0 + 16 qb + c
+  // scores and running maxima are kept times log2(e): one multiply per score and the hardware's 2^x, instead of a
+  // multiply by the scale and exp(x) = 2^(x log2 e) with its own multiply; the log-sum-exp goes out in natural units
+  const float scale2 = scale * 1.44269504089f;
 
   // Q fragments: lane holds Q[q0 + 16 qb + c][32 ks + 8 g .. +7]
   bf16x8 qf[QB][KS];
@@ -85,14 +91,41 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
 
   for (int kt0 = 0; kt0 < L; kt0 += KT) {
     if (kt0 > 0) __syncthreads();
-    // ---- stage the key mask tile, then K, V of the 32-key groups that hold a visible key (a group
-    //      of masked keys has probability exactly 0: it is neither loaded nor multiplied)
+    // ---- stage the key mask tile and K, V of the tile's keys; the mask load and the K / V pieces are in flight
+    //      together (one memory latency, one barrier)
+    unsigned char mv = 0;
     if (tid < KT) {
       const int key = kt0 + tid;
-      unsigned char mv = 0;
       if (key < L) mv = keymask ? (keymask[(size_t)b * Ls + key] != 0) : 1;
-      Ms[tid] = mv;
     }
+    // K and V rows go to LDS by LDS-DMA, 16 pieces per wave all in flight at once: a 1-KiB piece is 4 rows x 256 B,
+    // lane i lands at row i / 16, slot i % 16 and fetches the chunk that the swizzle keeps there. (Through registers,
+    // a thread's loads and LDS stores alternate and every piece waits out a memory latency of its own: 16 latencies
+    // per tile, which was most of this kernel's time at L = 128.) Rows past the end of the sequence read its last
+    // row instead of zeros: their keys are masked, P = 0 exactly, and 0 times a finite row is 0; pieces that lie
+    // wholly past the end are not fetched, and their 32-key group is not multiplied (no visible key). Chunks a row
+    // does not have (DH < 128) land in slots nobody reads.
+    {
+      const unsigned char* kbase = (const unsigned char*)(qkv + tb * row3 + (size_t)h * DH + d);
+      const unsigned char* vbase = kbase + (size_t)d * 2;
+      const unsigned lds_k = (unsigned)(size_t)(attn_lds*)Ks, lds_v = (unsigned)(size_t)(attn_lds*)Vs;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int piece = 8 * wave + j;                    // rows 4 piece .. 4 piece + 3: inside one 32-key group
+        if (kt0 + 32 * (piece >> 3) >= L) continue;        // the whole group lies past the end
+        const int row = 4 * piece + (lane >> 4);
+        int ch = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+        ch = ch < CPR ? ch : CPR - 1;
+        const int key = min(kt0 + row, L - 1);
+        const unsigned voff = (unsigned)(((size_t)key * row3 + ch * 8) * 2);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     ::"s"(lds_k + piece * 1024), "v"(voff), "s"(kbase) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     ::"s"(lds_v + piece * 1024), "v"(voff), "s"(vbase) : "memory", "m0");
+      }
+    }
+    if (tid < KT) Ms[tid] = mv;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     bool live[4];
 #pragma unroll
@@ -100,21 +133,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
       const u32x4 m0 = *(const u32x4*)(Ms + 32 * s4), m1 = *(const u32x4*)(Ms + 32 * s4 + 16);
       live[s4] = ((m0[0] | m0[1] | m0[2] | m0[3] | m1[0] | m1[1] | m1[2] | m1[3]) != 0u);
     }
-    for (int idx = tid; idx < KT * CPR; idx += 256) {
-      const int row = idx / CPR, ch = idx % CPR;
-      if (!live[row >> 5]) continue;
-      const int key = kt0 + row;
-      u32x4 kv = (u32x4){0u, 0u, 0u, 0u}, vv = (u32x4){0u, 0u, 0u, 0u};
-      if (key < L) {
-        const unsigned short* base = qkv + (tb + key) * row3 + (size_t)h * DH + ch * 8;
-        kv = *(const u32x4*)(base + d);
-        vv = *(const u32x4*)(base + 2 * d);
-      }
-      const int off = kv_off(row, ch);
-      *(u32x4*)(Ks + off) = kv;
-      *(u32x4*)(Vs + off) = vv;
-    }
-    __syncthreads();
 
     // ---- S^T tiles: s[qb][tile][r] <-> key_local = 32 (tile>>1) + 8 g + 4 (tile&1) + r, query c of block qb
     f32x4 s[QB][8];
@@ -146,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const bool vis = ((m4 >> (8 * r)) & 0xffu) != 0u;
-          const float v = vis ? s[qb][tile][r] * scale : -INFINITY;
+          const float v = vis ? s[qb][tile][r] * scale2 : -INFINITY;      // base-2 logarithm domain
           s[qb][tile][r] = v;
           mloc = fmaxf(mloc, v);
         }
@@ -156,13 +174,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
       const float m_new = fmaxf(m_run[qb], mloc);
       const bool dead = (m_new == -INFINITY);
       const float m_use = dead ? 0.f : m_new;
-      const float alpha = (m_run[qb] == -INFINITY) ? 0.f : __expf(m_run[qb] - m_use);
+      const float alpha = (m_run[qb] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run[qb] - m_use);
       float psum = 0.f;
 #pragma unroll
       for (int tile = 0; tile < 8; ++tile)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = __expf(s[qb][tile][r] - m_use);  // exp(-inf) = 0 for masked keys
+          const float pv = __builtin_amdgcn_exp2f(s[qb][tile][r] - m_use);  // 2^(-inf) = 0 for masked keys
           s[qb][tile][r] = pv;
           psum += pv;
         }
@@ -238,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
         *(u32x2*)(op + 16 * dt) = w;
       }
       if (lse_out != nullptr && g == 0)
-        lse_out[((size_t)b * H + h) * Ls + qrow] = l_run[qb] > 0.f ? (m_run[qb] + __logf(l_run[qb])) : -INFINITY;
+        lse_out[((size_t)b * H + h) * Ls + qrow] = l_run[qb] > 0.f ? (m_run[qb] * 0.69314718056f + __logf(l_run[qb])) : -INFINITY;
     }
   }
 }

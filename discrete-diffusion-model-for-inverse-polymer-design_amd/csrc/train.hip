@@ -525,18 +525,30 @@ __global__ __launch_bounds__(256) void colsum_kernel(const unsigned short* __res
 constexpr int AT = 128;     // rows per staged tile
 constexpr int AROW = 256;   // LDS row stride in bytes
 
+typedef __attribute__((address_space(3))) void bwd_lds;
+
+// A 128-row tile of an operand to LDS by LDS-DMA, all of a wave's pieces in flight at once (a 1-KiB piece = 4 rows x
+// 256 B; lane i lands at row i / 16, slot i % 16 and fetches the chunk the swizzle keeps there): one memory latency
+// per tile. (Through registers a thread's loads and LDS stores alternate and every piece waits out a latency of its
+// own; holding all pieces in registers first spills in these kernels.) Rows at or past `limit` read row limit - 1 instead of zeros (their probabilities are exactly 0, and
+// 0 times a finite row is 0); 32-row groups not wanted are not fetched. `src` = the operand's row `0` of this
+// sequence and head (wave-uniform), `wave` wave-uniform. The caller waits (s_waitcnt vmcnt(0)) before its barrier.
 template <int DH>
-__device__ __forceinline__ void stage_rows(unsigned char* dst, const unsigned short* src, size_t row_stride,
-                                           int first, int limit, int tid, unsigned groups = 0xfu) {
-  // (holding all of a thread's pieces in registers before the first LDS store, to pay one memory latency per tile
-  // instead of one per piece, spills in these kernels: 43 -> 185 us)
+__device__ __forceinline__ void stage_rows_dma(unsigned char* dst, const unsigned short* src, size_t row_stride, int first,
+                                               int limit, int lane, int wave, unsigned groups) {
   constexpr int CPR = DH / 8;
-  for (int idx = tid; idx < AT * CPR; idx += 256) {
-    const int row = idx / CPR, ch = idx % CPR;
-    if (!((groups >> (row >> 5)) & 1u)) continue;      // 32-row group not wanted
-    u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-    if (first + row < limit) v = *(const u32x4*)(src + (size_t)(first + row) * row_stride + ch * 8);
-    *(u32x4*)(dst + tile_off(row, ch)) = v;
+  const unsigned lds = (unsigned)(size_t)(bwd_lds*)dst;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int piece = 8 * wave + j;                      // rows 4 piece .. 4 piece + 3: inside one 32-row group
+    if (!((groups >> (piece >> 3)) & 1u)) continue;
+    const int row = 4 * piece + (lane >> 4);
+    int ch = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+    ch = ch < CPR ? ch : CPR - 1;
+    const int r = min(first + row, limit - 1);
+    const unsigned voff = (unsigned)(((size_t)r * row_stride + ch * 8) * 2);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 ::"s"(lds + piece * 1024), "v"(voff), "s"(src) : "memory", "m0");
   }
 }
 
@@ -559,7 +571,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned shor
   unsigned char* const Vs = smem + AT * AROW;
   unsigned char* const Ms = smem + 2 * AT * AROW;
   constexpr int KS = DH / 32, DT = DH / 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, c = lane & 15;
   const int b = blockIdx.z, h = blockIdx.y;
   const int d = H * DH;
@@ -602,21 +615,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const unsigned shor
 
   for (int kt0 = 0; kt0 < L; kt0 += AT) {
     if (kt0 > 0) __syncthreads();
+    // the mask load and the K / V pieces of the groups that begin before the end of the sequence are in flight together
+    unsigned char mv = 0;
     if (tid < AT) {
       const int key = kt0 + tid;
-      Ms[tid] = key < L ? (keymask ? (keymask[(size_t)b * Ls + key] != 0) : 1) : 0;
+      if (key < L) mv = keymask ? (keymask[(size_t)b * Ls + key] != 0) : 1;
     }
+    const unsigned by_len = (1u << min(4, (L - kt0 + 31) >> 5)) - 1u;
+    stage_rows_dma<DH>(Ks, qkv + tb * row3 + d + (size_t)h * DH, row3, kt0, L, lane, wave, by_len);
+    stage_rows_dma<DH>(Vs, qkv + tb * row3 + 2 * d + (size_t)h * DH, row3, kt0, L, lane, wave, by_len);
+    if (tid < AT) Ms[tid] = mv;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // 32-key groups without a visible key have P = 0 and dS = 0: not loaded, not multiplied
+    // 32-key groups without a visible key have P = 0 and dS = 0: not multiplied
     unsigned live = 0u;
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
       const u32x4 m0 = *(const u32x4*)(Ms + 32 * s4), m1 = *(const u32x4*)(Ms + 32 * s4 + 16);
       if ((m0[0] | m0[1] | m0[2] | m0[3] | m1[0] | m1[1] | m1[2] | m1[3]) != 0u) live |= 1u << s4;
     }
-    stage_rows<DH>(Ks, qkv + tb * row3 + d + (size_t)h * DH, row3, kt0, L, tid, live);
-    stage_rows<DH>(Vs, qkv + tb * row3 + 2 * d + (size_t)h * DH, row3, kt0, L, tid, live);
-    __syncthreads();
     float pv[4][8], dv[4][8];
     float psum = 0.f;
 #pragma unroll
@@ -709,7 +726,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const unsigned sho
   float* const Lq = (float*)(smem + 2 * AT * AROW);
   float* const Dl = Lq + AT;
   constexpr int KS = DH / 32, DT = DH / 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, c = lane & 15;
   const int b = blockIdx.z, h = blockIdx.y;
   const int d = H * DH;
@@ -752,13 +770,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const unsigned sho
     // 32-query groups past the end of the sequence have P = 0 and dS = 0: not staged, not multiplied
     const int ngrp = min(4, (L - qt0 + 31) >> 5);
     const unsigned qgroups = (1u << ngrp) - 1u;
-    stage_rows<DH>(Qs, qkv + tb * row3 + (size_t)h * DH, row3, qt0, L, tid, qgroups);
-    stage_rows<DH>(Ds, dO + tb * d + (size_t)h * DH, (size_t)d, qt0, L, tid, qgroups);
+    stage_rows_dma<DH>(Qs, qkv + tb * row3 + (size_t)h * DH, row3, qt0, L, lane, wave, qgroups);
+    stage_rows_dma<DH>(Ds, dO + tb * d + (size_t)h * DH, (size_t)d, qt0, L, lane, wave, qgroups);
     if (tid < AT) {
       const int q = qt0 + tid;
       Lq[tid] = q < L ? lse[((size_t)b * H + h) * Ls + q] : INFINITY;
       Dl[tid] = q < L ? delta[((size_t)b * H + h) * Ls + q] : 0.f;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (!wave_live) continue;
     // Keep decisions of the lane's key against this lane's 32 queries of the tile (bit i <-> query 8 g + 32 (i >> 3) +
