@@ -275,9 +275,10 @@ class _TrainWeights:
         _ck(_lib.lib().bd_multi_cast_bf16(_lib.ptr(self.jobs), self.n_jobs, self.max_rows, self.max_cols, _s()),
             "bd_multi_cast_bf16")
 
-    def unpad_gradients(self, gbuf):
-        """pad_grads -> the parameters' gradient buffers (``gbuf(param)``), one launch. The job table is rebuilt only
-        when a destination moved (gradients bound to the optimizer's flat buffer keep their addresses)."""
+    def unpad_gradients(self, gbuf, first_layer=0, end_layer=None):
+        """pad_grads -> the parameters' gradient buffers (``gbuf(param)``) for the layers [first_layer, end_layer), one
+        launch. The job table is rebuilt only when a destination moved (gradients bound to the optimizer's flat
+        buffer keep their addresses)."""
         dsts = [gbuf(p) for _, p, *_ in self.unpad]
         key = tuple(t.data_ptr() for t in dsts)
         if key != self._unpad_key:
@@ -288,7 +289,13 @@ class _TrainWeights:
             self._unpad_key = key
             self._unpad_dims = (len(jobs), max(j.rows for j in jobs), max(j.cols for j in jobs))
         n, mr, mc = self._unpad_dims
-        _ck(_lib.lib().bd_multi_unpad_add_f32(_lib.ptr(self._unpad_jobs), n, mr, mc, _s()), "bd_multi_unpad_add_f32")
+        per_layer = n // len(self.layers)              # the table is in layer order, the same jobs for every layer
+        end_layer = len(self.layers) if end_layer is None else end_layer
+        if end_layer <= first_layer:
+            return
+        first = C.c_void_p(self._unpad_jobs.data_ptr() + first_layer * per_layer * C.sizeof(_lib.CastJob))
+        _ck(_lib.lib().bd_multi_unpad_add_f32(first, (end_layer - first_layer) * per_layer, mr, mc, _s()),
+            "bd_multi_unpad_add_f32")
 
 
 def _train_weights(model):
@@ -465,6 +472,7 @@ class _BackboneFn(torch.autograd.Function):
             for t_ in dqkvb:                  # filler rows: never written by the attention backward, read by the wgrad
                 t_[pk.n_real:].zero_()
         pending, handed = [], {}
+        unpadded_from = [n_layers]            # layers from here up were un-padded early, for the tail hook
 
         def hand_over(li):
             if not pending:
@@ -482,9 +490,24 @@ class _BackboneFn(torch.autograd.Function):
             done = torch.cuda.Event()
             done.record(side)
             handed[li] = done
-            if direct and _TAIL_HOOK[0] is not None and li == _TAIL_HOOK[1]:
-                with torch.cuda.stream(side):       # the side stream's order covers this layer's main-stream work too
-                    _TAIL_HOOK[0]()
+
+        def tail_hook(li):
+            """Every gradient of the layers >= li is enqueued (main stream: this layer's kernels; second stream: the
+            weight-gradient GEMMs handed over so far): un-pad the upper layers' attention gradients, then call the hook
+            on a stream whose order covers both."""
+            if side is not None:
+                ready = torch.cuda.Event()
+                ready.record(main)
+                side.wait_event(ready)
+                _STREAM[0] = side_h
+            try:
+                if padded:
+                    tw.unpad_gradients(gbuf, first_layer=li)
+                    unpadded_from[0] = li
+            finally:
+                _STREAM[0] = main_h
+            with torch.cuda.stream(side if side is not None else main):
+                _TAIL_HOOK[0]()
 
         def wgrad_side(li, dY, X, dW, N, K, db):
             if side is None:
@@ -542,8 +565,8 @@ class _BackboneFn(torch.autograd.Function):
                     dx_bf16=dy_next if li > stop_layer else None, drop=drop, site=max(0, 4 * (li - 1) + 3))
             if side is not None:
                 hand_over(li)
-            elif direct and _TAIL_HOOK[0] is not None and li == _TAIL_HOOK[1]:
-                _TAIL_HOOK[0]()
+            if direct and _TAIL_HOOK[0] is not None and li == _TAIL_HOOK[1]:
+                tail_hook(li)
         if need_embed and drop is not None:
             _ck(lib.bd_dropout_f32(_lib.ptr(dx), _lib.ptr(dx), M, d, _dp(drop), 0, _s()), "bd_dropout_f32")
         if need_embed and pk is None:
@@ -562,7 +585,7 @@ class _BackboneFn(torch.autograd.Function):
         if side is not None:
             main.wait_stream(side)       # every gradient is complete before autograd / the optimizer go on
         if padded:
-            tw.unpad_gradients(gbuf)
+            tw.unpad_gradients(gbuf, end_layer=unpadded_from[0])
         out = [None, None, None, None, None, None]
         for p in params:
             g = grads.get(p)

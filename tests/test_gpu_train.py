@@ -468,13 +468,16 @@ def test_optimizer_picks_up_gradients_unbound_by_model_zero_grad(gpu_device):
         opt.step()
 
 
-def test_tail_hook_fires_when_the_upper_layers_gradients_are_complete(gpu_device):
+@pytest.mark.parametrize("heads", [3, 8])
+def test_tail_hook_fires_when_the_upper_layers_gradients_are_complete(gpu_device, heads):
     """The data-parallel exchange starts the all-reduce of flat_grad[split:] from a hook inside the backward pass:
     what the hook sees there (a copy enqueued on the hook's stream) must already be the final gradients of the
-    layers >= split, the final norm and the vocabulary head, while the head of the buffer is still being written."""
+    layers >= split, the final norm and the vocabulary head, while the head of the buffer is still being written.
+    With 8 heads of 48 the attention projections' gradients are accumulated zero-padded and must have joined the
+    flat buffer for those layers before the hook, and exactly once."""
     from bidiff.parallel import tail_split_offset
     dev = gpu_device
-    cfg = dict(RI.SMALL_CFG, vocab_size=39, num_layers=4, dropout=0.1)
+    cfg = dict(RI.SMALL_CFG, vocab_size=39, num_layers=4, dropout=0.1, num_heads=heads)
     torch.manual_seed(7)
     bb = DiffusionBackbone(**cfg)
     model = DiscreteMaskingDiffusion(bb, num_steps=cfg["num_diffusion_steps"], mask_token_id=1, pad_token_id=0,
@@ -500,6 +503,18 @@ def test_tail_hook_fires_when_the_upper_layers_gradients_are_complete(gpu_device
             assert len(seen) == 1
             assert torch.equal(seen[0][0], opt.flat_grad[off:]), "tail complete when the hook fires"
             assert not torch.equal(seen[0][1], opt.flat_grad[:off]), "head still in progress"
+        # the same backward pass without the hook gives the same gradients (nothing added twice, nothing left out)
+        bb.dropout = 0.0               # no dropout decisions: the two passes differ in nothing but the hook
+        grads = []
+        for hk in (hook, None):
+            AG.set_tail_ready_hook(hk, 2)
+            opt.zero_grad()
+            torch.manual_seed(5)       # same timesteps and corruption
+            model(ids, attn)["loss"].backward()
+            torch.cuda.synchronize()
+            grads.append(opt.flat_grad.clone())
+        assert rel(grads[0].cpu(), grads[1].cpu()) < 1e-4
+        AG.set_tail_ready_hook(hook, 2)
         # gradients not bound to the flat buffer: autograd accumulates after the backward pass, no early hook
         model.zero_grad()
         seen.clear()
