@@ -14,6 +14,54 @@ import torch.nn as nn
 from .. import _lib
 
 
+class _Outputs(dict):
+    """The forward pass's result dict with entries that are built on first access (``deferred``: key -> function).
+    Every way of looking at the dict sees them: indexing, ``get``, ``in``, iteration, ``keys`` / ``items`` / ``values``."""
+
+    def __init__(self, eager, deferred):
+        super().__init__(eager)
+        self._deferred = dict(deferred)
+
+    def _build_all(self):
+        for key in list(self._deferred):
+            self[key] = self._deferred.pop(key)()
+
+    def __missing__(self, key):
+        if key in self._deferred:
+            self[key] = self._deferred.pop(key)()
+            return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._deferred
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def __iter__(self):
+        self._build_all()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        return dict.__len__(self) + len(self._deferred)
+
+    def keys(self):
+        self._build_all()
+        return dict.keys(self)
+
+    def items(self):
+        self._build_all()
+        return dict.items(self)
+
+    def values(self):
+        self._build_all()
+        return dict.values(self)
+
+    def __repr__(self):
+        self._build_all()
+        return dict.__repr__(self)
+
+
 class DiscreteMaskingDiffusion(nn.Module):
     def __init__(
         self,
@@ -111,8 +159,8 @@ class DiscreteMaskingDiffusion(nn.Module):
             from ..training.autograd import packed_training_loss
             loss, logits = packed_training_loss(self, noisy_ids, bb._check_inputs(noisy_ids, timesteps), attention_mask,
                                                 input_ids, mask_indicator, lengths)
-            return {"loss": loss, "logits": logits, "noisy_ids": noisy_ids, "mask_indicator": mask_indicator,
-                    "timesteps": timesteps}
+            return _Outputs({"loss": loss, "noisy_ids": noisy_ids, "mask_indicator": mask_indicator,
+                             "timesteps": timesteps}, {"logits": logits})
         logits = self.backbone(noisy_ids, timesteps, attention_mask)
         loss = self._compute_loss(logits, input_ids, mask_indicator, attention_mask)
         return {

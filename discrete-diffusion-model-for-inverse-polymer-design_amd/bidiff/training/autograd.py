@@ -73,11 +73,13 @@ def _ln(x, g, b, out_bf16, stats, M, d, eps):
                                 M, d, eps, _s()), "bd_layernorm")
 
 
-def _ln_bwd(dy, x, stats, g, dres, dx, dg, db, M, d, dx_bf16=None, drop=None, site=0):
-    """dx (fp32) and optionally its bf16 copy (dropped at ``site`` when ``drop`` is given) in one pass."""
+def _ln_bwd(dy, x, stats, g, dres, dx, dg, db, M, d, dx_bf16=None, drop=None, site=0, drop_dx=False):
+    """dx (fp32) and optionally its bf16 copy (dropped at ``site`` when ``drop`` is given) in one pass;
+    ``drop_dx``: no bf16 copy, the dropout applies to dx itself."""
+    use_drop = drop if (dx_bf16 is not None or drop_dx) else None
     _ck(_lib.lib().bd_layernorm_bwd_cast(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(stats), _lib.ptr(g), _lib.ptr(dres),
                                          _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), M, d, _lib.ptr(dx_bf16),
-                                         _dp(drop if dx_bf16 is not None else None), site, _s()), "bd_layernorm_bwd")
+                                         _dp(use_drop), site, _s()), "bd_layernorm_bwd")
 
 
 def _wgrad(dY, X, dW, M, N, K, db=None):
@@ -525,6 +527,7 @@ class _BackboneFn(torch.autograd.Function):
 
         datt = torch.empty(M, aw, dtype=bf, device=dev)
         delta = torch.empty(B, H, L, device=dev)
+        embed_drop_done = False
         for li, blk, w, s in zip(reversed(range(len(model.layers))), reversed(model.layers), reversed(tw.layers),
                                  reversed(ctx.saved)):
             if li < stop_layer:
@@ -561,13 +564,16 @@ class _BackboneFn(torch.autograd.Function):
             else:   # rows of the padded projections (the q rows were scaled by qfix in the forward: undone when un-padding)
                 wgrad_side(li, dqkv, s["h1"], tw.pad_views[li]["w"], 3 * aw, d, tw.pad_views[li]["b"])
             _gemm(dqkv, w["wqkvT"], None, dh_buf, M, d, d, 3 * aw, d, 0)
+            # (the lowest layer's dx is the gradient of the embedding dropout's output: dropped in the same pass)
+            embed_drop_done = li == 0 and need_embed and drop is not None and d % 8 == 0
             _ln_bwd(dh_buf, s["x_in"], s["st1"], blk.norm1.weight, dx, dx, gbuf(blk.norm1.weight), gbuf(blk.norm1.bias), M, d,
-                    dx_bf16=dy_next if li > stop_layer else None, drop=drop, site=max(0, 4 * (li - 1) + 3))
+                    dx_bf16=dy_next if li > stop_layer else None, drop=drop, site=max(0, 4 * (li - 1) + 3),
+                    drop_dx=embed_drop_done)
             if side is not None:
                 hand_over(li)
             if direct and _TAIL_HOOK[0] is not None and li == _TAIL_HOOK[1]:
                 tail_hook(li)
-        if need_embed and drop is not None:
+        if need_embed and drop is not None and not embed_drop_done:
             _ck(lib.bd_dropout_f32(_lib.ptr(dx), _lib.ptr(dx), M, d, _dp(drop), 0, _s()), "bd_dropout_f32")
         if need_embed and pk is None:
             _ck(lib.bd_embed_bwd(_lib.ptr(dx), _lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(gbuf(model.token_embedding.weight)),
@@ -629,8 +635,9 @@ class _MaskedCE(torch.autograd.Function):
         ctx.save_for_backward(lg, tg, ind, lse, sums)
         ctx.am = am
         ctx.shape = logits.shape
-        cnt = sums[1]
-        return torch.where(cnt > 0, sums[0] / cnt.clamp(min=1e-30), torch.zeros_like(cnt))
+        loss = torch.empty((), device=dev)
+        _ck(_lib.lib().bd_masked_ce_finish(_lib.ptr(sums), _lib.ptr(loss), _s()), "bd_masked_ce_finish")
+        return loss
 
     @staticmethod
     def backward(ctx, gout):
@@ -652,21 +659,31 @@ def masked_cross_entropy(logits, targets, mask_indicator, attention_mask=None):
 
 
 def packed_training_loss(diffusion, noisy_ids, timesteps, attention_mask, targets, mask_indicator, lengths=None):
-    """Denoiser + masked CE on the packed rows of the batch. Returns (loss, logits [B, L, V]): the loss and its
-    gradients equal the padded computation's (padded rows contribute to neither); the returned logits are a
-    detached copy with zeros at the rows that were left out."""
+    """Denoiser + masked CE on the packed rows of the batch. Returns (loss, logits): the loss and its gradients
+    equal the padded computation's (padded rows contribute to neither); ``logits()`` builds the [B, L, V] logits, a
+    detached copy with zeros at the rows that were left out (a training loop never looks at them, and writing
+    B * L * V floats per step costs as much as two of the step's GEMMs)."""
     backbone = diffusion.backbone
     B, L = noisy_ids.shape
     if lengths is None:
         lengths = RowPacking.lengths_from_mask(attention_mask)
     pk = RowPacking(lengths, B, L, noisy_ids.device)
     logits_p = backbone_forward_train(backbone, noisy_ids, timesteps, attention_mask, packing=pk)
-    idx, filler = pk.gather_index()
-    tg = targets.reshape(-1)[idx]
-    ind = mask_indicator.reshape(-1)[idx] & ~filler
-    am = attention_mask.reshape(-1)[idx]
-    loss = masked_cross_entropy(logits_p, tg, ind, am)
-    with torch.no_grad():
-        full = torch.zeros(B * L, logits_p.shape[-1], device=logits_p.device, dtype=logits_p.dtype)
-        full.index_copy_(0, idx[:pk.n_real], logits_p.detach()[:pk.n_real])
-    return loss, full.view(B, L, -1)
+    # targets and loss flags of the packed rows (attention mask folded into the flag, fillers flagged off): one launch
+    tg = torch.empty(pk.n_rows, dtype=torch.long, device=noisy_ids.device)
+    ind = torch.empty(pk.n_rows, dtype=torch.uint8, device=noisy_ids.device)
+    ind_src = mask_indicator.contiguous()
+    ind_src = ind_src.view(torch.uint8) if ind_src.dtype == torch.bool else (ind_src != 0).to(torch.uint8)
+    _ck(_lib.lib().bd_pack_targets(_lib.ptr(targets.to(torch.long).contiguous()), _lib.ptr(ind_src),
+                                   _lib.ptr(attention_mask.to(torch.long).contiguous()), _lib.ptr(pk.rowmap), pk.n_rows,
+                                   _lib.ptr(tg), _lib.ptr(ind), _s()), "bd_pack_targets")
+    loss = masked_cross_entropy(logits_p, tg, ind, None)
+
+    def full_logits():
+        """[B, L, V] copy of the packed logits, zeros at the rows that were left out (built when somebody asks)."""
+        with torch.no_grad():
+            idx, _ = pk.gather_index()
+            full = torch.zeros(B * L, logits_p.shape[-1], device=logits_p.device, dtype=logits_p.dtype)
+            full.index_copy_(0, idx[:pk.n_real], logits_p.detach()[:pk.n_real])
+        return full.view(B, L, -1)
+    return loss, full_logits

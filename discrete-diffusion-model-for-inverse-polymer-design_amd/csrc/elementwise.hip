@@ -420,6 +420,35 @@ extern "C" int bd_build_rowmap(const int* cu_seqlens, int B, int L, int n_rows, 
   return bd_check_launch("bd_build_rowmap");
 }
 
+// targets / loss flags of the packed rows in one pass: the flag folds the attention mask in, filler rows get none
+static __global__ __launch_bounds__(256) void pack_targets_kernel(const long long* __restrict__ targets,
+                                                           const unsigned char* __restrict__ indicator,
+                                                           const long long* __restrict__ attn,
+                                                           const int* __restrict__ rowmap, int n_rows,
+                                                           long long* __restrict__ tg_out,
+                                                           unsigned char* __restrict__ ind_out) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_rows) return;
+  const int src = rowmap[r];
+  long long tg = 0;
+  unsigned char on = 0;
+  if (src >= 0) {
+    tg = targets[src];
+    on = (indicator[src] != 0 && (attn == nullptr || attn[src] != 0)) ? 1 : 0;
+  }
+  tg_out[r] = tg;
+  ind_out[r] = on;
+}
+
+extern "C" int bd_pack_targets(const long long* targets, const unsigned char* indicator, const long long* attention_mask,
+                               const int* rowmap, int n_rows, long long* targets_out, unsigned char* indicator_out,
+                               void* stream) {
+  BD_REQUIRE(targets && indicator && rowmap && targets_out && indicator_out && n_rows > 0, "bd_pack_targets: bad argument");
+  hipLaunchKernelGGL(pack_targets_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, targets,
+                     indicator, attention_mask, rowmap, n_rows, targets_out, indicator_out);
+  return bd_check_launch("bd_pack_targets");
+}
+
 extern "C" int bd_layernorm(const float* x, const float* gamma, const float* beta, void* out_bf16,
                             float* out_f32, float* stats, int M, int d, float eps, void* stream) {
   BD_REQUIRE(x && gamma && beta && (out_bf16 || out_f32), "bd_layernorm: null operand");

@@ -68,6 +68,11 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
   }
 }
 
+// loss = sums[0] / sums[1], an exact zero when no row carried weight
+__global__ void ce_finish_kernel(const float* __restrict__ sums, float* __restrict__ loss) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) loss[0] = sums[1] > 0.f ? sums[0] / sums[1] : 0.f;
+}
+
 // dlogits = g * w / count * (softmax - onehot); zero rows where w == 0 or count == 0
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits,
                                                      const long long* __restrict__ targets,
@@ -179,6 +184,12 @@ __global__ __launch_bounds__(512) void layernorm_bwd_kernel(const unsigned short
           if (dres != nullptr) {
             const f32x4 r = ((const f32x4*)(dres + (size_t)row * d))[i];
             o[0] += r[0]; o[1] += r[1]; o[2] += r[2]; o[3] += r[3];
+          }
+          if (dx_bf16 == nullptr && drop.thr != 0u) {      // no bf16 copy: the dropout applies to dx itself
+            const bd_philox_out w = bd_drop_block(drop, (uint32_t)row, (uint32_t)(i >> 1));
+            const int j0 = 4 * (i & 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] *= bd_drop_factor(drop, w, j0 + e);
           }
           ((f32x4*)(dx + (size_t)row * d))[i] = o;
           if (dx_bf16 != nullptr) {      // the next branch's incoming gradient: bf16 copy, optionally dropped
@@ -879,7 +890,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const unsigned sho
 // Rows that are exactly zero (padded positions carry no gradient) add nothing.
 constexpr int EB_MAXL = 1024;    // longest sequence of embed_bwd_seq_kernel
 
-__global__ __launch_bounds__(256) void embed_bwd_seq_kernel(const float* __restrict__ dx, const long long* __restrict__ ids,
+__global__ __launch_bounds__(1024) void embed_bwd_seq_kernel(const float* __restrict__ dx, const long long* __restrict__ ids,
                                                             const long long* __restrict__ tsteps, float* __restrict__ dtok,
                                                             float* __restrict__ dtim, int Ls, int d, int pad_id,
                                                             int vocab, int n_timesteps, const int* __restrict__ cu) {
@@ -892,9 +903,10 @@ __global__ __launch_bounds__(256) void embed_bwd_seq_kernel(const float* __restr
   __shared__ short sord[EB_MAXL];
   const int b = blockIdx.x;
   const float* g = dx + (cu ? (size_t)cu[b] : (size_t)b * Ls) * d;
-  for (int l = threadIdx.x; l < L; l += 256) sid[l] = (int)ids[(size_t)b * Ls + l];
+  const int nthr = blockDim.x;
+  for (int l = threadIdx.x; l < L; l += nthr) sid[l] = (int)ids[(size_t)b * Ls + l];
   __syncthreads();
-  for (int l = threadIdx.x; l < L; l += 256) {
+  for (int l = threadIdx.x; l < L; l += nthr) {
     const int mine = sid[l];
     int rank = 0;
     for (int j = 0; j < L; ++j) rank += (sid[j] < mine) || (sid[j] == mine && j < l);
@@ -905,15 +917,15 @@ __global__ __launch_bounds__(256) void embed_bwd_seq_kernel(const float* __restr
   const long long ts = tsteps[b];
   const bool ts_ok = ts >= 0 && ts < n_timesteps;
   float* c = dtim + (size_t)(ts_ok ? ts : 0) * d;
-  for (int i = threadIdx.x; i < d; i += 256) {
+  for (int i = threadIdx.x; i < d; i += nthr) {
     float tsum = 0.f, run = 0.f;
     int run_id = -1;
-    for (int r0 = 0; r0 < L; r0 += 8) {
-      float v[8];
+    for (int r0 = 0; r0 < L; r0 += 16) {
+      float v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = r0 + u < L ? g[(size_t)sord[r0 + u] * d + i] : 0.f;
+      for (int u = 0; u < 16; ++u) v[u] = r0 + u < L ? g[(size_t)sord[r0 + u] * d + i] : 0.f;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 16; ++u) {
         if (r0 + u >= L) break;
         const int id = sid[sord[r0 + u]];
         if (id != run_id) {
@@ -932,17 +944,45 @@ __global__ __launch_bounds__(256) void embed_bwd_seq_kernel(const float* __restr
 
 __global__ __launch_bounds__(256) void embed_bwd_pos_varlen_kernel(const float* __restrict__ dx, float* __restrict__ dpos,
                                                                    const int* __restrict__ cu, int B, int d) {
-  // packed rows: position l of sequence b is row cu[b] + l when l < its length
+  // packed rows: position l of sequence b is row cu[b] + l when l < its length. One wave per sequence, four
+  // sequences of a wave in flight (a loop that visits the sequences one after another waits out a memory latency
+  // for each), every wave adds its own sums to the table.
   const int l = blockIdx.x;
   const int per = (B + gridDim.y - 1) / gridDim.y;
   const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
-  for (int i = threadIdx.x; i < d; i += 256) {
-    float sum = 0.f;
-    for (int b = b0; b < b1; ++b) {
-      const int r0 = cu[b];
-      if (l < cu[b + 1] - r0) sum += dx[((size_t)r0 + l) * d + i];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = d >> 2;
+  for (int i0 = 0; i0 < nv; i0 += 128) {      // two float4 columns per lane and pass
+    const int ia = i0 + lane, ib = i0 + 64 + lane;
+    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+    for (int b = b0 + wave; b < b1; b += 16) {
+      f32x4 va[4], vb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int bb = b + 4 * u;
+        va[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        vb[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (bb < b1) {
+          const int r0 = cu[bb];
+          if (l < cu[bb + 1] - r0) {
+            const f32x4* row = (const f32x4*)(dx + ((size_t)r0 + l) * d);
+            if (ia < nv) va[u] = row[ia];
+            if (ib < nv) vb[u] = row[ib];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        sa[0] += va[u][0]; sa[1] += va[u][1]; sa[2] += va[u][2]; sa[3] += va[u][3];
+        sb[0] += vb[u][0]; sb[1] += vb[u][1]; sb[2] += vb[u][2]; sb[3] += vb[u][3];
+      }
     }
-    if (sum != 0.f) atomicAdd(dpos + (size_t)l * d + i, sum);
+    float* out = dpos + (size_t)l * d;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (ia < nv && sa[e] != 0.f) atomicAdd(out + 4 * ia + e, sa[e]);
+      if (ib < nv && sb[e] != 0.f) atomicAdd(out + 4 * ib + e, sb[e]);
+    }
   }
 }
 
@@ -1186,6 +1226,12 @@ extern "C" int bd_masked_ce_fwd(const float* logits, const long long* targets, c
   return bd_check_launch("bd_masked_ce_fwd");
 }
 
+extern "C" int bd_masked_ce_finish(const float* sums, float* loss, void* stream) {
+  BD_REQUIRE(sums && loss, "bd_masked_ce_finish: null operand");
+  hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, loss);
+  return bd_check_launch("bd_masked_ce_finish");
+}
+
 extern "C" int bd_masked_ce_bwd(const float* logits, const long long* targets, const unsigned char* indicator,
                                 const long long* attention_mask, const float* lse, const float* sums,
                                 const float* grad_out, float* dlogits, int M, int V, void* stream) {
@@ -1205,7 +1251,7 @@ extern "C" int bd_layernorm_bwd_cast(const void* dy_bf16, const float* x, const 
   BD_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 2048, "bd_layernorm_bwd: bad shape M=%d d=%d", M, d);
   bd_drop_args da;
   BD_REQUIRE(bd_drop_make(drop, site, &da), "bd_layernorm_bwd: dropout p=%g outside [0, 1)", (double)drop->p);
-  BD_REQUIRE(da.thr == 0u || (dx_bf16 != nullptr && d % 8 == 0), "bd_layernorm_bwd: dropout applies to the bf16 output (d %% 8 == 0)");
+  BD_REQUIRE(da.thr == 0u || d % 8 == 0, "bd_layernorm_bwd: dropout needs d %% 8 == 0");
   // Rows per wave: about 320 workgroups of 8 waves, at most 16, an even number above 1. Every workgroup ends with
   // the sum over its eight waves and 2 d atomics, a fixed cost per workgroup, so more, smaller workgroups are slower
   // (10 k rows: 63 us at 1 row per wave, 30 us at 4 or 8) and fewer leave CUs idle. Neither a second launch that
@@ -1443,10 +1489,12 @@ static int embed_bwd_impl(const float* dx, const long long* ids, const long long
   BD_REQUIRE(L <= max_pos, "bd_embed_bwd: sequence length %d exceeds max_position_embeddings %d", L, max_pos);
   BD_REQUIRE(B > 0 && L > 0 && L <= EB_MAXL && d > 0, "bd_embed_bwd: bad shape B=%d L=%d d=%d", B, L, d);
   bd_prof_scope prof(stream, 2.0 * (double)B * L * d * 4.0, BD_PROF_EMBED);
-  hipLaunchKernelGGL(embed_bwd_seq_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, dx, ids, timesteps, dtok,
-                     dtime, L, d, pad_id, vocab, n_timesteps, cu);
+  // one thread per column: the longest sequence's row loop, not the column loop, sets the kernel's length
+  const int seq_threads = d >= 1024 ? 1024 : (d + 63) / 64 * 64;
+  hipLaunchKernelGGL(embed_bwd_seq_kernel, dim3((unsigned)B), dim3(seq_threads), 0, (hipStream_t)stream, dx, ids, timesteps,
+                     dtok, dtime, L, d, pad_id, vocab, n_timesteps, cu);
   // enough workgroups to fill the chip: the batch is cut into slices when there are few positions
-  const int slices = L >= 512 ? 1 : (512 + L - 1) / L;
+  const int slices = L >= 1024 ? 1 : (1024 + L - 1) / L;
   if (cu)
     hipLaunchKernelGGL(embed_bwd_pos_varlen_kernel, dim3((unsigned)L, (unsigned)(slices < B ? slices : B)), dim3(256), 0,
                        (hipStream_t)stream, dx, dpos, cu, B, d);

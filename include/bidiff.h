@@ -301,6 +301,9 @@ int bd_gemm_bf16_drop(const void* A, const void* W, const float* bias, void* out
  * replaces DiscreteMaskingDiffusion._compute_loss, src/model/diffusion.py:169-209, and its autograd. */
 int bd_masked_ce_fwd(const float* logits, const long long* targets, const unsigned char* indicator,
                      const long long* attention_mask, float* lse, float* sums, int M, int V, void* stream);
+/* loss[0] = sums[0] / sums[1], exactly 0 when sums[1] == 0 (the reference returns a zero that is still attached to
+ * the graph when no position is both masked and attended, src/model/diffusion.py:203-205). */
+int bd_masked_ce_finish(const float* sums, float* loss, void* stream);
 int bd_masked_ce_bwd(const float* logits, const long long* targets, const unsigned char* indicator,
                      const long long* attention_mask, const float* lse, const float* sums,
                      const float* grad_out, float* dlogits, int M, int V, void* stream);
@@ -312,7 +315,8 @@ int bd_layernorm_bwd(const void* dy_bf16, const float* x, const float* stats, co
 
 /* The same, also writing dx rounded to bf16 (dx_bf16 [M, d]; what the next branch's GEMMs read),
  * with optional dropout of that copy: dx_bf16 = bf16(dx * keep / (1 - p)) at (row m, column n) of `site`
- * (the backward of the dropout after fc2, src/model/backbone.py:100). */
+ * (the backward of the dropout after fc2, src/model/backbone.py:100). With dx_bf16 == NULL and a dropout given,
+ * dx itself is dropped (the backward of the embedding dropout, src/model/backbone.py:247, where no GEMM follows). */
 int bd_layernorm_bwd_cast(const void* dy_bf16, const float* x, const float* stats, const float* gamma,
                           const float* dres, float* dx, float* dgamma, float* dbeta, int M, int d,
                           void* dx_bf16, const bd_dropout* drop, unsigned site, void* stream);
@@ -370,6 +374,11 @@ int bd_attention_bwd_drop(const void* qkv, const unsigned char* keymask, const v
 
 /* rowmap[r] = b * L + l for packed row r (the logical token it holds), -1 for filler rows. */
 int bd_build_rowmap(const int* cu_seqlens, int B, int L, int n_rows, int* rowmap, void* stream);
+/* Targets and loss flags of the packed rows: targets_out[r] = targets[rowmap[r]] (0 for fillers), indicator_out[r] = 1
+ * where rowmap[r] >= 0, indicator[rowmap[r]] != 0 and attention_mask[rowmap[r]] != 0 (attention_mask may be null):
+ * the valid-position product of src/model/diffusion.py:190-200 on the rows that are computed. */
+int bd_pack_targets(const long long* targets, const unsigned char* indicator, const long long* attention_mask,
+                    const int* rowmap, int n_rows, long long* targets_out, unsigned char* indicator_out, void* stream);
 /* bd_embed_drop on packed rows: x[r] = embedding sum of logical token rowmap[r] (ids [B, L], timesteps [B]); filler
  * rows become zeros. (src/model/backbone.py:234-247) */
 int bd_embed_rows(const long long* ids, const long long* timesteps, const int* rowmap, const float* tok_emb,

@@ -51,7 +51,8 @@ def run(model, dev, ids, attn, t, u, packed, lengths=None, seed=0x1234, step=4):
         p_.grad = None
     noisy, ind = model.forward_process(ids.to(dev), t.to(dev), attn.to(dev), uniforms=u.to(dev))
     if packed:
-        loss, logits = AG.packed_training_loss(model, noisy, t.to(dev), attn.to(dev), ids.to(dev), ind, lengths)
+        loss, logits_fn = AG.packed_training_loss(model, noisy, t.to(dev), attn.to(dev), ids.to(dev), ind, lengths)
+        logits = logits_fn()
     else:
         logits = bb(noisy, t.to(dev), attn.to(dev))
         loss = model._compute_loss(logits, ids.to(dev), ind, attn.to(dev))
@@ -135,3 +136,35 @@ def test_packed_training_steps_and_module_forward(gpu_device):
     assert out["loss"].item() == 0.0
     with pytest.raises(ValueError):
         model(ids.to(dev), attn.to(dev), lengths=[L + 1] * B)
+
+
+def test_forward_outputs_build_the_padded_logits_on_demand(gpu_device):
+    """model(ids, attn) on the packed path returns the reference's dict (loss, logits, noisy_ids, mask_indicator,
+    timesteps); the [B, L, V] logits are written only when somebody looks at them, and every way of looking does."""
+    dev = gpu_device
+    B, L = 12, 40
+    cfg, model, sd, ids, attn, t, u, lens = setup(dev, B, L, 0.0)
+    torch.manual_seed(3)
+    out = model(ids.to(dev), attn.to(dev))
+    assert "logits" in out and len(out) == 5
+    assert not dict.__contains__(out, "logits")          # not built yet
+    out["loss"].backward()
+    assert not dict.__contains__(out, "logits")
+    lg = out["logits"]
+    assert lg.shape == (B, L, cfg["vocab_size"]) and not lg.requires_grad
+    assert out.get("logits") is lg and out.get("nothing", 7) == 7
+    torch.manual_seed(3)
+    out2 = model(ids.to(dev), attn.to(dev))
+    assert set(out2.keys()) == {"loss", "logits", "noisy_ids", "mask_indicator", "timesteps"}
+    assert torch.equal(out2["logits"], lg) and torch.equal(out2["noisy_ids"], out["noisy_ids"])
+    # rows behind a sequence's last attended position are zeros, the others are the denoiser's logits
+    model.skip_padded_rows = False
+    torch.manual_seed(3)
+    ref = model(ids.to(dev), attn.to(dev))
+    model.skip_padded_rows = True
+    assert isinstance(ref["logits"], torch.Tensor)
+    assert abs(float(ref["loss"].detach()) - float(out["loss"].detach())) < 2e-3
+    for b in range(B):
+        assert torch.all(lg[b, lens[b]:] == 0)
+        if lens[b]:
+            assert (lg[b, :lens[b]] - ref["logits"][b, :lens[b]]).abs().max() < 6e-2
