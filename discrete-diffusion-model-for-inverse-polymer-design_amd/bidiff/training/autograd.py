@@ -428,6 +428,7 @@ class _BackboneFn(torch.autograd.Function):
             return torch.zeros(*shape, device=dev)
 
         dh_buf = torch.empty(M, d, dtype=bf, device=dev)
+        head_job = None
         if ctx.mode == 1:
             # the incoming gradient is that of the final-norm output itself
             _to_bf16(dlogits.reshape(M, d).float().contiguous(), dh_buf)
@@ -436,10 +437,8 @@ class _BackboneFn(torch.autograd.Function):
             dl = torch.zeros(M, tw.vpad, dtype=bf, device=dev)
             dl[:, :V] = dlogits.reshape(M, V)
             dwout = zeros(tw.vpad, d)
-            _wgrad(dl, ctx.hf, dwout, M, tw.vpad, d)
-            if direct and model.output_proj.weight.requires_grad:
-                model.output_proj.weight.grad.add_(dwout[:V])
-            else:
+            head_job = (dl, ctx.hf, dwout, M, tw.vpad, d, None)      # launched with the weight-gradient GEMMs below
+            if not (direct and model.output_proj.weight.requires_grad):
                 grads[model.output_proj.weight] = dwout[:V]
             _gemm(dl, tw.woutT, None, dh_buf, M, d, d, tw.vpad, d, 0)
         dx = torch.empty(M, d, device=dev)
@@ -489,6 +488,9 @@ class _BackboneFn(torch.autograd.Function):
             finally:
                 _STREAM[0] = main_h
             pending.clear()
+            if head_add:          # the vocabulary head's padded gradient joins the parameter's behind its GEMM
+                with torch.cuda.stream(side):
+                    head_add.pop()()
             done = torch.cuda.Event()
             done.record(side)
             handed[li] = done
@@ -517,6 +519,18 @@ class _BackboneFn(torch.autograd.Function):
             pending.append((dY, X, dW, M, N, K, db))
             if li == stop_layer:
                 hand_over(li)
+
+        head_add = []
+        if head_job is not None:
+            direct_head = direct and model.output_proj.weight.requires_grad
+            if side is None:
+                _wgrad(*head_job[:6])
+                if direct_head:
+                    model.output_proj.weight.grad.add_(head_job[2][:V])
+            else:
+                pending.append(head_job)
+                if direct_head:
+                    head_add.append(lambda: model.output_proj.weight.grad.add_(head_job[2][:V]))
 
         # every LayerNorm backward also emits the bf16 gradient the next branch reads (with the fc2-output
         # dropout of that branch folded in), so dx is not read again just to be cast
@@ -589,6 +603,7 @@ class _BackboneFn(torch.autograd.Function):
                                         int(model.pad_token_id), V, model.max_position_embeddings,
                                         model.num_diffusion_steps + 1, _s()), "bd_embed_bwd_varlen")
         if side is not None:
+            hand_over(-1)                # whatever no layer handed over (a model without trainable blocks)
             main.wait_stream(side)       # every gradient is complete before autograd / the optimizer go on
         if padded:
             tw.unpad_gradients(gbuf, end_layer=unpadded_from[0])
