@@ -126,6 +126,8 @@ SIGNATURES = {
     "bd_masked_ce_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, VP]),
     "bd_layernorm_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, VP]),
     "bd_layernorm_bwd_cast": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, VP, VP, C.c_uint, VP]),
+    "bd_layernorm_bwd_parts": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP, VP, C.c_uint, VP]),
+    "bd_layernorm_parts_finish": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP]),
     "bd_decode_ids": (C.c_int, [VP, C.c_int, C.c_int, VP, VP, C.c_int, VP, VP, C.c_int, VP]),
     "bd_gemm_wgrad_bf16": (C.c_int, [VP, C.c_int, VP, C.c_int, VP, C.c_int, C.c_int, C.c_int, VP]),
     "bd_gemm_wgrad_segments": (C.c_int, [VP, C.c_int, VP, C.c_int, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),

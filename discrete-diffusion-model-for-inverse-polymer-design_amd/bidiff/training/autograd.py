@@ -73,13 +73,65 @@ def _ln(x, g, b, out_bf16, stats, M, d, eps):
                                 M, d, eps, _s()), "bd_layernorm")
 
 
-def _ln_bwd(dy, x, stats, g, dres, dx, dg, db, M, d, dx_bf16=None, drop=None, site=0, drop_dx=False):
+def _ln_bwd(dy, x, stats, g, dres, dx, dg, db, M, d, dx_bf16=None, drop=None, site=0, drop_dx=False, parts=None):
     """dx (fp32) and optionally its bf16 copy (dropped at ``site`` when ``drop`` is given) in one pass;
     ``drop_dx``: no bf16 copy, the dropout applies to dx itself."""
     use_drop = drop if (dx_bf16 is not None or drop_dx) else None
+    if parts is not None:      # gamma / beta sums into the next slot of the copies; parts.finish() adds them to dg / db
+        _ck(_lib.lib().bd_layernorm_bwd_parts(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(stats), _lib.ptr(g), _lib.ptr(dres),
+                                              _lib.ptr(dx), _lib.ptr(parts.slot(dg, db)), parts.n_parts, M, d,
+                                              _lib.ptr(dx_bf16), _dp(use_drop), site, _s()), "bd_layernorm_bwd_parts")
+        return
     _ck(_lib.lib().bd_layernorm_bwd_cast(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(stats), _lib.ptr(g), _lib.ptr(dres),
                                          _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), M, d, _lib.ptr(dx_bf16),
                                          _dp(use_drop), site, _s()), "bd_layernorm_bwd")
+
+
+class _LnPartsJob(C.Structure):
+    _fields_ = [("parts", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
+
+
+class _LnParts:
+    """Copies of the LayerNorm gamma / beta gradient rows that one backward pass's LayerNorm launches add to
+    (``n_parts`` copies per launch: an address then takes n_parts times fewer atomics, and those retire one after
+    another), and the launch that adds them to the parameters' gradients. ``slot`` hands out the copies in call
+    order; ``finish`` covers the slots handed out since the last ``finish`` and leaves them zeroed."""
+    n_parts = 8
+
+    def __init__(self, n_slots, d, device):
+        self.buf = torch.zeros(n_slots, self.n_parts, 2, d, device=device)
+        self.d = d
+        self.used, self.done, self.dst = 0, 0, []
+        self._tables = {}
+        self.dirty = False
+
+    def begin(self):
+        if self.dirty:                 # a backward pass that did not reach its last finish()
+            self.buf.zero_()
+        self.used, self.done, self.dst = 0, 0, []
+        self.dirty = True
+
+    def slot(self, dgamma, dbeta):
+        self.dst.append((dgamma, dbeta))
+        self.used += 1
+        return self.buf[self.used - 1]
+
+    def finish(self, last=False):
+        if self.used > self.done:
+            key = (self.done,) + tuple(t.data_ptr() for pair in self.dst[self.done:self.used] for t in pair)
+            table = self._tables.get(key)
+            if table is None:
+                jobs = [_LnPartsJob(self.buf[k].data_ptr(), self.dst[k][0].data_ptr(), self.dst[k][1].data_ptr())
+                        for k in range(self.done, self.used)]
+                arr = (_LnPartsJob * len(jobs))(*jobs)
+                if len(self._tables) > 8:
+                    self._tables.clear()
+                table = self._tables[key] = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.buf.device)
+            _ck(_lib.lib().bd_layernorm_parts_finish(_lib.ptr(table), self.used - self.done, self.n_parts, self.d, _s()),
+                "bd_layernorm_parts_finish")
+            self.done = self.used
+        if last:
+            self.dirty = False
 
 
 def _wgrad(dY, X, dW, M, N, K, db=None):
@@ -271,11 +323,18 @@ class _TrainWeights:
         self.max_rows = max(j.rows for j in jobs)
         self.max_cols = max(j.cols for j in jobs)
         self._unpad_key, self._unpad_jobs = None, None
+        self._ln_parts = None
         self.refresh(model)
 
     def refresh(self, model):
         _ck(_lib.lib().bd_multi_cast_bf16(_lib.ptr(self.jobs), self.n_jobs, self.max_rows, self.max_cols, _s()),
             "bd_multi_cast_bf16")
+
+    def ln_parts(self, d, device):
+        """The backward pass's LayerNorm partial-sum copies (two LayerNorms per layer and the final one)."""
+        if self._ln_parts is None:
+            self._ln_parts = _LnParts(2 * len(self.layers) + 1, d, device)
+        return self._ln_parts
 
     def unpad_gradients(self, gbuf, first_layer=0, end_layer=None):
         """pad_grads -> the parameters' gradient buffers (``gbuf(param)``) for the layers [first_layer, end_layer), one
@@ -508,6 +567,7 @@ class _BackboneFn(torch.autograd.Function):
                 if padded:
                     tw.unpad_gradients(gbuf, first_layer=li)
                     unpadded_from[0] = li
+                lnp.finish()             # the LayerNorm gamma / beta sums of the layers >= li
             finally:
                 _STREAM[0] = main_h
             with torch.cuda.stream(side if side is not None else main):
@@ -535,9 +595,11 @@ class _BackboneFn(torch.autograd.Function):
         # every LayerNorm backward also emits the bf16 gradient the next branch reads (with the fc2-output
         # dropout of that branch folded in), so dx is not read again just to be cast
         top = (n_layers - 1) % len(dyb) if n_layers else 0
+        lnp = tw.ln_parts(d, dev)
+        lnp.begin()
         _ln_bwd(dh_buf, ctx.x_last, ctx.stf, model.final_norm.weight, None, dx, gbuf(model.final_norm.weight),
                 gbuf(model.final_norm.bias), M, d, dx_bf16=dyb[top] if n_layers else None, drop=drop,
-                site=max(0, 4 * (n_layers - 1) + 3))
+                site=max(0, 4 * (n_layers - 1) + 3), parts=lnp)
 
         datt = torch.empty(M, aw, dtype=bf, device=dev)
         delta = torch.empty(B, H, L, device=dev)
@@ -558,7 +620,7 @@ class _BackboneFn(torch.autograd.Function):
             wgrad_side(li, du, s["h2"], gbuf(blk.ffn.fc1.weight), F, d, gbuf(blk.ffn.fc1.bias))
             _gemm(du, w["w1T"], None, dh_buf, M, d, d, F, d, 0)
             _ln_bwd(dh_buf, s["x_mid"], s["st2"], blk.norm2.weight, dx, dx, gbuf(blk.norm2.weight), gbuf(blk.norm2.bias), M, d,
-                    dx_bf16=dy2)
+                    dx_bf16=dy2, parts=lnp)
             # x_mid = x_in + out_proj(attention(qkv(LN1(x_in))))
             # (zero-padded heads: the padded copies' gradients go to tw.pad_grads and are added to the parameters' at the end)
             wgrad_side(li, dy2, s["att"], tw.pad_views[li]["o"] if padded else gbuf(a.out_proj.weight), d, aw,
@@ -582,7 +644,7 @@ class _BackboneFn(torch.autograd.Function):
             embed_drop_done = li == 0 and need_embed and drop is not None and d % 8 == 0
             _ln_bwd(dh_buf, s["x_in"], s["st1"], blk.norm1.weight, dx, dx, gbuf(blk.norm1.weight), gbuf(blk.norm1.bias), M, d,
                     dx_bf16=dy_next if li > stop_layer else None, drop=drop, site=max(0, 4 * (li - 1) + 3),
-                    drop_dx=embed_drop_done)
+                    drop_dx=embed_drop_done, parts=lnp)
             if side is not None:
                 hand_over(li)
             if direct and _TAIL_HOOK[0] is not None and li == _TAIL_HOOK[1]:
@@ -607,6 +669,7 @@ class _BackboneFn(torch.autograd.Function):
             main.wait_stream(side)       # every gradient is complete before autograd / the optimizer go on
         if padded:
             tw.unpad_gradients(gbuf, end_layer=unpadded_from[0])
+        lnp.finish(last=True)
         out = [None, None, None, None, None, None]
         for p in params:
             g = grads.get(p)
@@ -689,8 +752,9 @@ def packed_training_loss(diffusion, noisy_ids, timesteps, attention_mask, target
     ind = torch.empty(pk.n_rows, dtype=torch.uint8, device=noisy_ids.device)
     ind_src = mask_indicator.contiguous()
     ind_src = ind_src.view(torch.uint8) if ind_src.dtype == torch.bool else (ind_src != 0).to(torch.uint8)
-    _ck(_lib.lib().bd_pack_targets(_lib.ptr(targets.to(torch.long).contiguous()), _lib.ptr(ind_src),
-                                   _lib.ptr(attention_mask.to(torch.long).contiguous()), _lib.ptr(pk.rowmap), pk.n_rows,
+    tg_src = targets.to(torch.long).contiguous()          # (converted copies stay referenced until the launch is queued)
+    am_src = attention_mask.to(torch.long).contiguous()
+    _ck(_lib.lib().bd_pack_targets(_lib.ptr(tg_src), _lib.ptr(ind_src), _lib.ptr(am_src), _lib.ptr(pk.rowmap), pk.n_rows,
                                    _lib.ptr(tg), _lib.ptr(ind), _s()), "bd_pack_targets")
     loss = masked_cross_entropy(logits_p, tg, ind, None)
 

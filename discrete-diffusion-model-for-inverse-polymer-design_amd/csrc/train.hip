@@ -112,7 +112,7 @@ __global__ __launch_bounds__(512) void layernorm_bwd_kernel(const unsigned short
                                                             const float* dres, float* dx,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             int M, int d, unsigned short* __restrict__ dx_bf16,
-                                                            bd_drop_args drop, int rpw) {
+                                                            bd_drop_args drop, int rpw, int n_parts, int part_stride) {
   // rpw rows per wave (host: enough workgroups to fill the chip), walked two at a time so that the second row's
   // loads and reductions overlap the first's (a wave that handles its rows one after another spends its time
   // waiting: each row is a load, two dependent wave reductions and a store)
@@ -225,10 +225,37 @@ __global__ __launch_bounds__(512) void layernorm_bwd_kernel(const unsigned short
     red[i] = t;       // column i is read and written by this thread only
   }
   __syncthreads();
+  // n_parts > 1: the sums go to one of n_parts copies of the two rows (part_stride floats apart), which the caller
+  // adds up later: atomics on one address retire one after another, and with one copy every address takes one from
+  // every workgroup, all at the end of the kernel
+  const size_t part = (size_t)(blockIdx.x % n_parts) * part_stride;
   for (int i = threadIdx.x; i < d; i += 512) {
-    atomicAdd(dgamma + i, red[i]);
-    atomicAdd(dbeta + i, red[d + i]);
+    atomicAdd(dgamma + part + i, red[i]);
+    atomicAdd(dbeta + part + i, red[d + i]);
   }
+}
+
+// dgamma += sum of the parts' first rows, dbeta += sum of their second rows; the parts are left zeroed
+struct LnPartsJob { float* parts; float* dgamma; float* dbeta; };
+__global__ __launch_bounds__(256) void ln_parts_finish_kernel(const LnPartsJob* __restrict__ jobs, int n_parts, int d) {
+  // one thread per element of a job's two rows; the copies' values are all requested before the first is used
+  const LnPartsJob job = jobs[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * d) return;
+  float* const src = job.parts + i;
+  const size_t stride = 2 * (size_t)d;
+  float t = 0.f;
+  int k = 0;
+  for (; k + 8 <= n_parts; k += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(k + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { t += v[u]; src[(k + u) * stride] = 0.f; }
+  }
+  for (; k < n_parts; ++k) { t += src[k * stride]; src[k * stride] = 0.f; }
+  float* dst = i < d ? job.dgamma + i : job.dbeta + (i - d);
+  *dst += t;
 }
 
 // =====================================================================================
@@ -1244,9 +1271,35 @@ extern "C" int bd_masked_ce_bwd(const float* logits, const long long* targets, c
   return bd_check_launch("bd_masked_ce_bwd");
 }
 
+static int layernorm_bwd_impl(const void* dy_bf16, const float* x, const float* stats, const float* gamma,
+                              const float* dres, float* dx, float* dgamma, float* dbeta, int M, int d, void* dx_bf16,
+                              const bd_dropout* drop, unsigned site, int n_parts, int part_stride, void* stream);
+
 extern "C" int bd_layernorm_bwd_cast(const void* dy_bf16, const float* x, const float* stats, const float* gamma,
                                      const float* dres, float* dx, float* dgamma, float* dbeta, int M, int d,
                                      void* dx_bf16, const bd_dropout* drop, unsigned site, void* stream) {
+  return layernorm_bwd_impl(dy_bf16, x, stats, gamma, dres, dx, dgamma, dbeta, M, d, dx_bf16, drop, site, 1, 0, stream);
+}
+
+extern "C" int bd_layernorm_bwd_parts(const void* dy_bf16, const float* x, const float* stats, const float* gamma,
+                                      const float* dres, float* dx, float* parts, int n_parts, int M, int d,
+                                      void* dx_bf16, const bd_dropout* drop, unsigned site, void* stream) {
+  BD_REQUIRE(parts != nullptr && n_parts >= 1 && n_parts <= 64, "bd_layernorm_bwd_parts: bad parts (n=%d)", n_parts);
+  return layernorm_bwd_impl(dy_bf16, x, stats, gamma, dres, dx, parts, parts + d, M, d, dx_bf16, drop, site, n_parts,
+                            2 * d, stream);
+}
+
+extern "C" int bd_layernorm_parts_finish(const bd_ln_parts_job* jobs, int n_jobs, int n_parts, int d, void* stream) {
+  BD_REQUIRE(jobs != nullptr && n_jobs > 0 && n_parts >= 1 && d > 0, "bd_layernorm_parts_finish: bad argument");
+  static_assert(sizeof(bd_ln_parts_job) == sizeof(LnPartsJob), "job layout");
+  hipLaunchKernelGGL(ln_parts_finish_kernel, dim3((unsigned)((2 * d + 255) / 256), (unsigned)n_jobs), dim3(256), 0, (hipStream_t)stream,
+                     (const LnPartsJob*)jobs, n_parts, d);
+  return bd_check_launch("bd_layernorm_parts_finish");
+}
+
+static int layernorm_bwd_impl(const void* dy_bf16, const float* x, const float* stats, const float* gamma,
+                              const float* dres, float* dx, float* dgamma, float* dbeta, int M, int d, void* dx_bf16,
+                              const bd_dropout* drop, unsigned site, int n_parts, int part_stride, void* stream) {
   BD_REQUIRE(dy_bf16 && x && stats && gamma && dx && dgamma && dbeta, "bd_layernorm_bwd: null operand");
   BD_REQUIRE(M > 0 && d > 0 && d % 4 == 0 && d <= 2048, "bd_layernorm_bwd: bad shape M=%d d=%d", M, d);
   bd_drop_args da;
@@ -1271,7 +1324,7 @@ extern "C" int bd_layernorm_bwd_cast(const void* dy_bf16, const float* x, const 
   do {                                                                                                          \
     BD_SET_MAX_LDS((layernorm_bwd_kernel<NV>), lds);                                                            \
     hipLaunchKernelGGL(layernorm_bwd_kernel<NV>, grid, block, lds, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d, ob, \
-                       da, rpw);                                                                                \
+                       da, rpw, n_parts, part_stride);                                                          \
   } while (0)
   if (nv <= 1) BD_LNB(1);
   else if (nv <= 2) BD_LNB(2);

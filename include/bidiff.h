@@ -321,6 +321,17 @@ int bd_layernorm_bwd_cast(const void* dy_bf16, const float* x, const float* stat
                           const float* dres, float* dx, float* dgamma, float* dbeta, int M, int d,
                           void* dx_bf16, const bd_dropout* drop, unsigned site, void* stream);
 
+/* bd_layernorm_bwd_cast with the gamma / beta sums spread over n_parts copies: workgroup w adds to rows
+ * parts[w % n_parts][0][d] (gamma) and parts[w % n_parts][1][d] (beta) of a caller-owned, zeroed [n_parts, 2, d] buffer
+ * (one address then takes n_parts times fewer atomics, which retire one after another). bd_layernorm_parts_finish adds
+ * the copies of several such buffers to their dgamma / dbeta destinations in one launch and leaves them zeroed.
+ * (autograd of nn.LayerNorm, src/model/backbone.py:126,128,254) */
+typedef struct bd_ln_parts_job { float* parts; float* dgamma; float* dbeta; } bd_ln_parts_job;
+int bd_layernorm_bwd_parts(const void* dy_bf16, const float* x, const float* stats, const float* gamma,
+                           const float* dres, float* dx, float* parts, int n_parts, int M, int d,
+                           void* dx_bf16, const bd_dropout* drop, unsigned site, void* stream);
+int bd_layernorm_parts_finish(const bd_ln_parts_job* jobs, int n_jobs, int n_parts, int d, void* stream);
+
 /* dW[N,K] += dY[M,N]^T * X[M,K] (bf16 in, fp32 accumulate with atomics); N, K multiples of 128.
  * (autograd of nn.Linear weights, src/model/backbone.py:25-28,91-92,195). */
 int bd_gemm_wgrad_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, int M, int N, int K,

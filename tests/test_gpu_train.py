@@ -695,3 +695,77 @@ def test_training_weight_copies_follow_the_parameters(gpu_device):
     assert torch.equal(tw.woutT[:, :V], bb.output_proj.weight.t().bfloat16()) and (tw.woutT[:, V:] == 0).all()
     same = AG._train_weights(bb)
     assert same is tw
+
+
+def test_pack_targets_gathers_targets_and_folds_the_masks(gpu_device):
+    """bd_pack_targets: packed row r takes the target of logical token rowmap[r]; its loss flag is on where the token
+    was masked AND attended (diffusion.py:190-200), off for filler rows."""
+    dev = gpu_device
+    rs = np.random.RandomState(5)
+    B, L, n_rows = 7, 19, 96
+    tg = rs.randint(0, 800, size=B * L).astype(np.int64)
+    ind = rs.rand(B * L) < 0.5
+    am = (rs.rand(B * L) < 0.8).astype(np.int64)
+    rowmap = np.full(n_rows, -1, dtype=np.int32)
+    real = rs.permutation(B * L)[:80]
+    rowmap[:80] = np.sort(real)
+    lib = _lib.lib()
+    tg_d, ind_d = torch.from_numpy(tg).to(dev), torch.from_numpy(ind).to(dev).view(torch.uint8)
+    am_d, rm_d = torch.from_numpy(am).to(dev), torch.from_numpy(rowmap).to(dev)
+    for with_mask in (True, False):
+        out_t = torch.full((n_rows,), -7, dtype=torch.long, device=dev)
+        out_i = torch.full((n_rows,), 9, dtype=torch.uint8, device=dev)
+        rc = lib.bd_pack_targets(_lib.ptr(tg_d), _lib.ptr(ind_d), _lib.ptr(am_d) if with_mask else None, _lib.ptr(rm_d),
+                                 n_rows, _lib.ptr(out_t), _lib.ptr(out_i), _lib.stream_handle())
+        assert rc == 0, lib.bd_last_error()
+        want_t = np.where(rowmap >= 0, tg[np.maximum(rowmap, 0)], 0)
+        want_i = (rowmap >= 0) & ind[np.maximum(rowmap, 0)] & ((am[np.maximum(rowmap, 0)] != 0) if with_mask else True)
+        assert np.array_equal(out_t.cpu().numpy(), want_t)
+        assert np.array_equal(out_i.cpu().numpy(), want_i.astype(np.uint8))
+
+
+def test_masked_ce_finish_divides_and_keeps_the_empty_case_at_zero(gpu_device):
+    dev = gpu_device
+    lib = _lib.lib()
+    for sums, want in (([6.0, 4.0], 1.5), ([0.0, 0.0], 0.0), ([3.0, 0.0], 0.0)):
+        s_ = torch.tensor(sums, device=dev)
+        out = torch.full((), -1.0, device=dev)
+        assert lib.bd_masked_ce_finish(_lib.ptr(s_), _lib.ptr(out), _lib.stream_handle()) == 0
+        assert float(out) == want
+
+
+@pytest.mark.parametrize("n_parts", [1, 8, 13])
+def test_layernorm_bwd_parts_sum_to_the_single_copy_result(gpu_device, n_parts):
+    """bd_layernorm_bwd_parts spreads the gamma / beta sums over copies; bd_layernorm_parts_finish ADDS their total to
+    the destinations (several jobs in one launch) and leaves the copies zeroed. dx does not depend on the split."""
+    import ctypes as C
+    dev = gpu_device
+    lib = _lib.lib()
+    P, st_ = _lib.ptr, _lib.stream_handle
+    M, d = 2048 + 24, 384
+    g = torch.Generator().manual_seed(11)
+    dy = torch.randn(M, d, generator=g).to(dev).bfloat16()
+    x = torch.randn(M, d, generator=g).to(dev)
+    stats = torch.stack([x.mean(1), 1 / (x.var(1, unbiased=False) + 1e-5).sqrt()], 1).contiguous()
+    gm = torch.randn(d, generator=g).to(dev)
+    dres = torch.randn(M, d, generator=g).to(dev)
+    dg0, db0 = torch.randn(d, generator=g).to(dev), torch.randn(d, generator=g).to(dev)
+    # single copy
+    dx1, dg1, db1 = dres.clone(), dg0.clone(), db0.clone()
+    assert lib.bd_layernorm_bwd_cast(P(dy), P(x), P(stats), P(gm), P(dx1), P(dx1), P(dg1), P(db1), M, d, None, None, 0, st_()) == 0
+    # two jobs through the copies: the same LayerNorm twice, into two destinations
+    parts = torch.zeros(2, n_parts, 2, d, device=dev)
+    dx2 = [dres.clone(), dres.clone()]
+    dst = [(dg0.clone(), db0.clone()), (torch.zeros(d, device=dev), torch.zeros(d, device=dev))]
+    for k in range(2):
+        assert lib.bd_layernorm_bwd_parts(P(dy), P(x), P(stats), P(gm), P(dx2[k]), P(dx2[k]), P(parts[k]), n_parts, M, d,
+                                          None, None, 0, st_()) == 0, lib.bd_last_error()
+    arr = (AG._LnPartsJob * 2)(*[AG._LnPartsJob(parts[k].data_ptr(), dst[k][0].data_ptr(), dst[k][1].data_ptr()) for k in range(2)])
+    jobs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    assert lib.bd_layernorm_parts_finish(P(jobs), 2, n_parts, d, st_()) == 0, lib.bd_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(dx1, dx2[0]) and torch.equal(dx1, dx2[1])
+    scale = float((dg1 - dg0).abs().max())
+    assert float((dst[0][0] - dg1).abs().max()) < 1e-4 * scale and float((dst[0][1] - db1).abs().max()) < 1e-4 * scale
+    assert float((dst[1][0] - (dg1 - dg0)).abs().max()) < 1e-4 * scale
+    assert float(parts.abs().max()) == 0.0
