@@ -433,7 +433,8 @@ class _BackboneFn(torch.autograd.Function):
             _ln(x_mid, blk.norm2.weight, blk.norm2.bias, s["h2"], s["st2"], M, d, eps)
             s["u"] = torch.empty(M, F, dtype=bf, device=dev)
             s["a"] = torch.empty(M, F, dtype=bf, device=dev)
-            _gemm(s["h2"], w["w1"], blk.ffn.fc1.bias, s["a"], M, F, F, d, F, 1, aux_out=s["u"], drop=drop,
+            # (s["u"] receives gelu'(pre-activation) times the dropout factor: the backward pass's multiplier)
+            _gemm(s["h2"], w["w1"], blk.ffn.fc1.bias, s["a"], M, F, F, d, F, 6, aux_out=s["u"], drop=drop,
                   site=4 * li + 2)
             x_out = torch.empty(M, d, device=dev)
             _gemm(s["a"], w["w2"], blk.ffn.fc2.bias, x_out, M, d, d, F, d, 2, aux_in=x_mid, drop=drop,
@@ -616,7 +617,7 @@ class _BackboneFn(torch.autograd.Function):
             dy2, du, dqkv = dy2b[li % nb], dub[li % nb], dqkvb[li % nb]
             # x_out = x_mid + drop(fc2(drop(gelu(fc1(LN2(x_mid))))))
             wgrad_side(li, dy, s["a"], gbuf(blk.ffn.fc2.weight), d, F, gbuf(blk.ffn.fc2.bias))
-            _gemm(dy, w["w2T"], None, du, M, F, F, d, F, 4, aux_in=s["u"], drop=drop, site=4 * li + 2)
+            _gemm(dy, w["w2T"], None, du, M, F, F, d, F, 7, aux_in=s["u"])
             wgrad_side(li, du, s["h2"], gbuf(blk.ffn.fc1.weight), F, d, gbuf(blk.ffn.fc1.bias))
             _gemm(du, w["w1T"], None, dh_buf, M, d, d, F, d, 0)
             _ln_bwd(dh_buf, s["x_mid"], s["st2"], blk.norm2.weight, dx, dx, gbuf(blk.norm2.weight), gbuf(blk.norm2.bias), M, d,

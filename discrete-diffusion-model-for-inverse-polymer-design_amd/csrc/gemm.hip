@@ -25,8 +25,11 @@ enum Epi : int {
   EPI_BIAS_RESID_F32 = 2,  // out fp32 += acc + bias        (residual stream, in place)
   EPI_F32 = 3,             // out fp32 = acc (+ bias if given), columns >= n_real dropped
   EPI_DGELU_BF16 = 4,      // out bf16 = (acc + bias) * gelu'(aux)   (aux = pre-activation, bf16)
-  EPI_AXPBY_BF16 = 5       // out bf16 = rn(rn(beta * aux) + rn(alpha * rn(acc))), aux bf16 laid out like out; every
+  EPI_AXPBY_BF16 = 5,      // out bf16 = rn(rn(beta * aux) + rn(alpha * rn(acc))), aux bf16 laid out like out; every
                            // product and the sum rounded to bf16 as a chain of bf16 tensor ops would
+  EPI_GELU_GRAD_BF16 = 6,  // out bf16 = drop(gelu(acc + bias)), aux_out bf16 = gelu'(acc + bias) * (the same dropout
+                           // factor): the forward pass leaves the backward pass its multiplier instead of the pre-activation
+  EPI_MUL_AUX_BF16 = 7     // out bf16 = (acc + bias) * aux_in   (aux_in bf16 laid out like out; backward of epilogue 6)
 };
 
 struct GemmArgs {
@@ -81,7 +84,39 @@ __device__ __forceinline__ void drop_factors16(const bd_drop_args& d, int m, int
 // of row m; applies the epilogue's activation / dropout / residual and stores.
 template <int EPI, bool DROP>
 __device__ __forceinline__ void epilogue_row(const GemmArgs& p, int m, int nb, float (&v)[16]) {
-  if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_DGELU_BF16 || EPI == EPI_AXPBY_BF16) {
+  if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_DGELU_BF16 || EPI == EPI_AXPBY_BF16 ||
+      EPI == EPI_GELU_GRAD_BF16 || EPI == EPI_MUL_AUX_BF16) {
+    if (EPI == EPI_GELU_GRAD_BF16) {
+      float f[16];
+      if (DROP) drop_factors16(p.drop, m, nb, f);
+      float gp[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float x = v[j], cdf = norm_cdf(x);
+        const float fj = DROP ? f[j] : 1.0f;
+        gp[j] = (cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x)) * fj;
+        v[j] = x * cdf * fj;
+      }
+      unsigned short* uo = (unsigned short*)p.aux_out + (size_t)m * p.ldc + nb;
+      u32x4 lo, hi;
+      lo[0] = bd_pack_bf16x2(gp[0], gp[1]);   lo[1] = bd_pack_bf16x2(gp[2], gp[3]);
+      lo[2] = bd_pack_bf16x2(gp[4], gp[5]);   lo[3] = bd_pack_bf16x2(gp[6], gp[7]);
+      hi[0] = bd_pack_bf16x2(gp[8], gp[9]);   hi[1] = bd_pack_bf16x2(gp[10], gp[11]);
+      hi[2] = bd_pack_bf16x2(gp[12], gp[13]); hi[3] = bd_pack_bf16x2(gp[14], gp[15]);
+      *(u32x4*)(uo) = lo;
+      *(u32x4*)(uo + 8) = hi;
+    }
+    if (EPI == EPI_MUL_AUX_BF16) {
+      const unsigned short* ui = (const unsigned short*)p.aux_in + (size_t)m * p.ldc + nb;
+      const u32x4 lo = *(const u32x4*)(ui), hi = *(const u32x4*)(ui + 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[2 * e] *= __uint_as_float(lo[e] << 16);
+        v[2 * e + 1] *= __uint_as_float(lo[e] & 0xffff0000u);
+        v[8 + 2 * e] *= __uint_as_float(hi[e] << 16);
+        v[8 + 2 * e + 1] *= __uint_as_float(hi[e] & 0xffff0000u);
+      }
+    }
     if (EPI == EPI_AXPBY_BF16) {
       const unsigned short* xi = (const unsigned short*)p.aux_in + (size_t)m * p.ldc + nb;
       const u32x4 lo = *(const u32x4*)(xi), hi = *(const u32x4*)(xi + 8);
@@ -111,7 +146,7 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& p, int m, int nb, f
 #pragma unroll
       for (int j = 0; j < 16; ++j) v[j] = gelu_erf(v[j]);
     }
-    if (DROP) {
+    if (DROP && EPI != EPI_GELU_GRAD_BF16) {
       float f[16];
       drop_factors16(p.drop, m, nb, f);
 #pragma unroll
@@ -578,7 +613,8 @@ extern "C" int bd_gemm_bf16_drop(const void* A, const void* W, const float* bias
                                  const void* aux_in, void* aux_out, int M, int n_pad, int n_real, int K,
                                  int ldc, int epilogue, const bd_dropout* drop, unsigned site, void* stream) {
   BD_REQUIRE(A && W && out, "bd_gemm_bf16: null operand");
-  BD_REQUIRE(epilogue >= 0 && epilogue <= 4, "bd_gemm_bf16: unknown epilogue %d", epilogue);
+  BD_REQUIRE((epilogue >= 0 && epilogue <= 4) || epilogue == EPI_GELU_GRAD_BF16 || epilogue == EPI_MUL_AUX_BF16,
+             "bd_gemm_bf16: unknown epilogue %d", epilogue);
   BD_REQUIRE(M > 0 && K > 0 && n_pad > 0, "bd_gemm_bf16: empty shape M=%d N=%d K=%d", M, n_pad, K);
   BD_REQUIRE(n_pad % BN == 0, "bd_gemm_bf16: weight rows %d must be padded to a multiple of %d", n_pad, BN);
   BD_REQUIRE(K % BK == 0, "bd_gemm_bf16: K=%d must be a multiple of %d", K, BK);
@@ -590,6 +626,8 @@ extern "C" int bd_gemm_bf16_drop(const void* A, const void* W, const float* bias
   a.A = (const unsigned short*)A; a.W = (const unsigned short*)W; a.bias = bias; a.out = out;
   a.aux_in = aux_in; a.aux_out = aux_out;
   BD_REQUIRE(epilogue != EPI_DGELU_BF16 || aux_in != nullptr, "bd_gemm_bf16: epilogue 4 needs the pre-activation");
+  BD_REQUIRE(epilogue != EPI_MUL_AUX_BF16 || aux_in != nullptr, "bd_gemm_bf16: epilogue 7 needs its multiplier");
+  BD_REQUIRE(epilogue != EPI_GELU_GRAD_BF16 || aux_out != nullptr, "bd_gemm_bf16: epilogue 6 needs aux_out");
   a.M = M; a.Npad = n_pad; a.K = K; a.n_real = n_real; a.ldc = ldc;
   a.sA = a.sW = a.sOut = 0; a.alpha = 1.f; a.beta = 0.f;
   a.tiles_n = n_pad / BN;
@@ -604,6 +642,7 @@ extern "C" int bd_gemm_bf16_drop(const void* A, const void* W, const float* bias
       case EPI_BIAS_GELU_BF16: return launch<EPI_BIAS_GELU_BF16, true>(a, s);
       case EPI_BIAS_RESID_F32: return launch<EPI_BIAS_RESID_F32, true>(a, s);
       case EPI_DGELU_BF16: return launch<EPI_DGELU_BF16, true>(a, s);
+      case EPI_GELU_GRAD_BF16: return launch<EPI_GELU_GRAD_BF16, true>(a, s);
       default: return bd_fail(BD_ERR_ARG, "bd_gemm_bf16: epilogue %d has no dropout", epilogue);
     }
   }
@@ -613,6 +652,8 @@ extern "C" int bd_gemm_bf16_drop(const void* A, const void* W, const float* bias
     case EPI_BIAS_RESID_F32: return launch<EPI_BIAS_RESID_F32>(a, s);
     case EPI_F32: return launch<EPI_F32>(a, s);
     case EPI_DGELU_BF16: return launch<EPI_DGELU_BF16>(a, s);
+    case EPI_GELU_GRAD_BF16: return launch<EPI_GELU_GRAD_BF16>(a, s);
+    case EPI_MUL_AUX_BF16: return launch<EPI_MUL_AUX_BF16>(a, s);
     default: return bd_fail(BD_ERR_ARG, "bd_gemm_bf16: unknown epilogue %d", epilogue);
   }
 }

@@ -224,6 +224,9 @@ int bd_pool_hidden(const void* hidden_bf16, const long long* attention_mask, flo
  *   epilogue 1: aux_out (optional) receives the bf16 pre-activation acc + bias (saved for backward)
  *   epilogue 2: aux_in (optional) is the fp32 residual input; out = aux_in + acc + bias
  *   epilogue 4: out bf16 = (acc + bias) * gelu'(aux_in), aux_in = bf16 pre-activation
+ *   epilogue 6: out bf16 = gelu(acc + bias), aux_out (required) = bf16 gelu'(acc + bias): the multiplier of the
+ *               backward pass instead of the pre-activation
+ *   epilogue 7: out bf16 = (acc + bias) * aux_in, aux_in = the bf16 multiplier epilogue 6 left
  * (no single reference line: the pieces autograd records for backbone.py:96-99,126-128). */
 int bd_gemm_bf16_aux(const void* A, const void* W, const float* bias, void* out, const void* aux_in,
                      void* aux_out, int M, int n_pad, int n_real, int K, int ldc, int epilogue,
@@ -289,6 +292,8 @@ int bd_embed_drop(const long long* ids, const long long* timesteps, const float*
  *   epilogue 1: out = drop(gelu(acc + bias))            (src/model/backbone.py:97-98)
  *   epilogue 2: out = aux_in + drop(acc + bias)         (src/model/backbone.py:99-100,128)
  *   epilogue 4: out = (acc + bias) * keep / (1 - p) * gelu'(aux_in)    (backward of epilogue 1)
+ *   epilogue 6: out = drop(gelu(acc + bias)), aux_out = gelu'(acc + bias) * keep / (1 - p) with the same decisions
+ *               (epilogue 7 without dropout is then the whole backward of src/model/backbone.py:97-98)
  * other epilogues reject a non-null drop with p > 0. */
 int bd_gemm_bf16_drop(const void* A, const void* W, const float* bias, void* out, const void* aux_in,
                       void* aux_out, int M, int n_pad, int n_real, int K, int ldc, int epilogue,

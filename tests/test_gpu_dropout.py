@@ -114,6 +114,22 @@ def test_gemm_epilogues_with_dropout(gpu_device, M, N, K):
     torch.nn.functional.gelu(ur).sum().backward()
     assert bool((o4[f == 0] == 0).all())
     assert rel(o4.float(), (A.float() @ W.float().t()) * f * ur.grad) < 1e-2
+    # epilogue 6: drop(gelu(.)) and the backward multiplier gelu'(.) * factor; epilogue 7 multiplies by it
+    for dr, ff in ((drop, f), (None, torch.ones_like(f))):
+        a6 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        t6 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        AG._gemm(A, W, bias, a6, M, N, N, K, N, 6, aux_out=t6, drop=dr, site=6)
+        pr = pre.clone().requires_grad_(True)
+        torch.nn.functional.gelu(pr).sum().backward()
+        assert rel(a6.float(), torch.nn.functional.gelu(pre) * ff) < 1e-2
+        assert bool((t6[ff == 0] == 0).all()) and bool((a6[ff == 0] == 0).all())
+        assert rel(t6.float(), pr.grad * ff) < 1e-2
+        o7 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        AG._gemm(A, W, None, o7, M, N, N, K, N, 7, aux_in=t6)
+        assert rel(o7.float(), (A.float() @ W.float().t()) * t6.float()) < 1e-2
+    rc = _lib.lib().bd_gemm_bf16_drop(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(a), None, None, M, N, N, K, N, 6,
+                                      None, 0, _s())
+    assert rc != 0, "epilogue 6 without aux_out"
     # an epilogue without a dropout form refuses
     rc = _lib.lib().bd_gemm_bf16_drop(_lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(a), None, None, M, N, N, K, N, 0,
                                       C.byref(drop), 6, _s())
