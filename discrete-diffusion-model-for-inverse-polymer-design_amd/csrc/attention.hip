@@ -198,6 +198,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
         const uint32_t prow = (uint32_t)(((size_t)b * H + h) * Ls + (q0 + 16 * qb + c));
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {      // tiles 2 s4, 2 s4 + 1 = keys key0 .. key0 + 7: one block
+          if (!live[s4]) continue;            // no visible key: the group's probabilities are zeros already
           const int key0 = kt0 + 32 * s4 + 8 * g;
           const bd_philox_out w = bd_drop_block(drop, prow, (uint32_t)(key0 >> 3));
 #pragma unroll
