@@ -76,9 +76,9 @@ def test_packed_rows_match_all_rows_and_oracle(gpu_device, p):
     kept = np.zeros(B * L, dtype=bool)
     kept[rowmap[rowmap >= 0]] = True
     assert kept.sum() == pk.n_real and np.array_equal(kept.reshape(B, L), np.arange(L)[None] < want_len[:, None])
-    # the lengths hint gives the same result bit for bit
+    # the lengths hint gives the same logits bit for bit (the loss is a sum of atomic adds: equal to rounding)
     _, _, loss_h, logits_h, g_h = run(model, dev, ids, attn, t, u, packed=True, lengths=want_len.tolist())
-    assert loss_h == loss_p and torch.equal(logits_h, logits_p)
+    assert abs(loss_h - loss_p) <= 1e-6 * abs(loss_p) and torch.equal(logits_h, logits_p)
     # fp32 restatement (with dropout: the same decision stream, token-row sites counted in packed order)
     stream = BR.DropoutStream(p, 0x1234, 4, rowmap=rowmap) if p > 0 else None
     ref_sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and k != "mask_schedule") for k, v in sd.items()}
