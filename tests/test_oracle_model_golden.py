@@ -124,3 +124,25 @@ def test_oracle_training_forward_replays_reference_rng_order():
         loss = BR.masked_ce(lg, torch.from_numpy(ids), torch.from_numpy(ind), torch.from_numpy(attn))
     assert np.abs(lg.numpy() - BLOB["fwd/logits"]).max() / np.abs(BLOB["fwd/logits"]).max() < 1e-5
     assert abs(loss.item() - float(BLOB["fwd/loss"])) < 1e-5
+
+
+def test_forward_result_dict_builds_deferred_entries_on_first_access():
+    """The training forward returns the reference's dict; entries that cost a pass over memory are built when first
+    read, and every way of reading a dict sees them."""
+    from bidiff.model.diffusion import _Outputs
+    calls = []
+
+    def build():
+        calls.append(1)
+        return "L"
+    out = _Outputs({"loss": 1.0, "timesteps": 2}, {"logits": build})
+    assert "logits" in out and "loss" in out and "nope" not in out and len(out) == 3
+    assert out["loss"] == 1.0 and calls == []
+    assert out.get("nope") is None and out.get("nope", 5) == 5 and calls == []
+    assert out["logits"] == "L" and out["logits"] == "L" and out.get("logits") == "L" and calls == [1]
+    out2 = _Outputs({"loss": 1.0}, {"logits": build})
+    assert sorted(out2.keys()) == ["logits", "loss"] and dict(out2.items())["logits"] == "L" and calls == [1, 1]
+    out3 = _Outputs({"loss": 1.0}, {"logits": build})
+    assert sorted(k for k in out3) == ["logits", "loss"] and "L" in out3.values()
+    with pytest.raises(KeyError):
+        out3["missing"]
