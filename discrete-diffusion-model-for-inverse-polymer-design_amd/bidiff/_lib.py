@@ -142,7 +142,8 @@ SIGNATURES = {
     "bd_attention_bwd_static": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "bd_build_rowmap": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, VP]),
     "bd_pack_targets": (C.c_int, [VP, VP, VP, VP, C.c_int, VP, VP, VP]),
-    "bd_masked_ce_finish": (C.c_int, [VP, VP, VP]),
+    "bd_masked_ce_finish": (C.c_int, [VP, VP, C.c_int, VP]),
+    "bd_masked_ce_fwd_parts": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP]),
     "bd_embed_rows": (C.c_int, [VP, VP, VP, VP, VP, VP, VP] + [C.c_int] * 6 + [VP, C.c_uint, VP]),
     "bd_attention_fwd_varlen": (C.c_int, [VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP, C.c_uint, VP]),
     "bd_attention_bwd_varlen": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP,

@@ -707,15 +707,16 @@ class _MaskedCE(torch.autograd.Function):
         tg = targets.to(torch.long).contiguous().view(-1)
         ind = indicator.to(torch.uint8).contiguous().view(-1)
         am = None if attention_mask is None else attention_mask.to(torch.long).contiguous().view(-1)
-        sums = torch.zeros(2, device=dev)
+        n_parts = 8          # the workgroups' sums go to eight pairs behind sums[0..1]; the finish launch adds them up
+        sums = torch.zeros(2 + 2 * n_parts, device=dev)
         lse = torch.empty(M, device=dev)
-        _ck(_lib.lib().bd_masked_ce_fwd(_lib.ptr(lg), _lib.ptr(tg), _lib.ptr(ind), _lib.ptr(am), _lib.ptr(lse),
-                                        _lib.ptr(sums), M, V, _s()), "bd_masked_ce_fwd")
+        _ck(_lib.lib().bd_masked_ce_fwd_parts(_lib.ptr(lg), _lib.ptr(tg), _lib.ptr(ind), _lib.ptr(am), _lib.ptr(lse),
+                                              _lib.ptr(sums), n_parts, M, V, _s()), "bd_masked_ce_fwd")
         ctx.save_for_backward(lg, tg, ind, lse, sums)
         ctx.am = am
         ctx.shape = logits.shape
         loss = torch.empty((), device=dev)
-        _ck(_lib.lib().bd_masked_ce_finish(_lib.ptr(sums), _lib.ptr(loss), _s()), "bd_masked_ce_finish")
+        _ck(_lib.lib().bd_masked_ce_finish(_lib.ptr(sums), _lib.ptr(loss), n_parts, _s()), "bd_masked_ce_finish")
         return loss
 
     @staticmethod

@@ -730,8 +730,13 @@ def test_masked_ce_finish_divides_and_keeps_the_empty_case_at_zero(gpu_device):
     for sums, want in (([6.0, 4.0], 1.5), ([0.0, 0.0], 0.0), ([3.0, 0.0], 0.0)):
         s_ = torch.tensor(sums, device=dev)
         out = torch.full((), -1.0, device=dev)
-        assert lib.bd_masked_ce_finish(_lib.ptr(s_), _lib.ptr(out), _lib.stream_handle()) == 0
+        assert lib.bd_masked_ce_finish(_lib.ptr(s_), _lib.ptr(out), 0, _lib.stream_handle()) == 0
         assert float(out) == want
+    # pairs behind the totals: added into sums[0..1], where the backward pass reads them
+    s_ = torch.tensor([0.0, 0.0, 1.0, 2.0, 5.0, 2.0, 0.0, 0.0], device=dev)
+    out = torch.full((), -1.0, device=dev)
+    assert lib.bd_masked_ce_finish(_lib.ptr(s_), _lib.ptr(out), 3, _lib.stream_handle()) == 0
+    assert float(out) == 1.5 and s_[:2].tolist() == [6.0, 4.0]
 
 
 @pytest.mark.parametrize("n_parts", [1, 8, 13])
