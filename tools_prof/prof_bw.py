@@ -32,13 +32,14 @@ for B in (4096, 262144):
 # masked CE at the training shape: rows with weight 0 are never read (about 30 % of the rows are non-pad, ~half of them masked)
 M, V = 32768, 803
 lg = torch.randn(M, V, device=dev); tg = torch.randint(0, V, (M,), device=dev)
-indm = (torch.rand(M, device=dev) < 0.16).to(torch.uint8); lse = torch.empty(M, device=dev); sums = torch.zeros(2, device=dev)
+indm = (torch.rand(M, device=dev) < 0.16).to(torch.uint8); lse = torch.empty(M, device=dev); sums = torch.zeros(2 + 16, device=dev)
 nz = int(indm.sum().item())
-timeit("ce_fwd_kernel M=32768 V=803 (16% rows live)", lambda: lib.bd_masked_ce_fwd(P(lg), P(tg), P(indm), None, P(lse), P(sums), M, V, s()),
+timeit("ce_fwd_kernel M=32768 V=803 (16% rows live)", lambda: lib.bd_masked_ce_fwd_parts(P(lg), P(tg), P(indm), None, P(lse), P(sums), 8, M, V, s()),
        nz * V * 4 + M * (8 + 1 + 4), note="reads only live rows")
 indf = torch.ones(M, dtype=torch.uint8, device=dev)
-timeit("ce_fwd_kernel M=32768 V=803 (all rows live)", lambda: lib.bd_masked_ce_fwd(P(lg), P(tg), P(indf), None, P(lse), P(sums), M, V, s()),
-       M * V * 4 + M * 13)
+timeit("ce_fwd_kernel M=32768 V=803 (all rows live)", lambda: lib.bd_masked_ce_fwd_parts(P(lg), P(tg), P(indf), None, P(lse), P(sums), 8, M, V, s()),
+       M * V * 4 + M * 13, note="sums into eight pairs; into one pair the 1024 workgroups' atomics queue on two addresses")
+lib.bd_masked_ce_finish(P(sums), P(torch.empty(1, device=dev)), 8, s())
 g1 = torch.ones(1, device=dev); dl = torch.empty_like(lg)
 timeit("ce_bwd_kernel M=32768 V=803 (all rows live)", lambda: lib.bd_masked_ce_bwd(P(lg), P(tg), P(indf), None, P(lse), P(sums), P(g1), P(dl), M, V, s()),
        2 * M * V * 4 + M * 17)
@@ -64,8 +65,9 @@ for M in (10240, 32768):
     xx = torch.randn(M, d, device=dev); st = torch.stack([xx.mean(1), xx.var(1, unbiased=False).add(1e-5).rsqrt()], 1).contiguous()
     dy = torch.randn(M, d, device=dev).bfloat16(); dx = torch.randn(M, d, device=dev); obb = torch.empty(M, d, dtype=torch.bfloat16, device=dev)
     dgm, dbt = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
-    timeit(f"layernorm_bwd_kernel M={M} d=384 (dx in place, dropped bf16 copy)",
-           lambda: lib.bd_layernorm_bwd_cast(P(dy), P(xx), P(st), P(gm), P(dx), P(dx), P(dgm), P(dbt), M, d, P(obb), C.byref(drop), 3, s()),
+    parts = torch.zeros(8, 2, d, device=dev)
+    timeit(f"layernorm_bwd_kernel M={M} d=384 (dx in place, dropped bf16 copy, gamma / beta sums into 8 copies)",
+           lambda: lib.bd_layernorm_bwd_parts(P(dy), P(xx), P(st), P(gm), P(dx), P(dx), P(parts), 8, M, d, P(obb), C.byref(drop), 3, s()),
            M * d * (2 + 4 + 4 + 4 + 2))
 # id -> text decode of a sampled batch
 from bidiff.sampling.decode import DeviceDecoder
