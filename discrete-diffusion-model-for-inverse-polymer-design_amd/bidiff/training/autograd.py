@@ -707,8 +707,8 @@ class _MaskedCE(torch.autograd.Function):
         tg = targets.to(torch.long).contiguous().view(-1)
         ind = indicator.to(torch.uint8).contiguous().view(-1)
         am = None if attention_mask is None else attention_mask.to(torch.long).contiguous().view(-1)
-        n_parts = 8          # the workgroups' sums go to eight pairs behind sums[0..1]; the finish launch adds them up
-        sums = torch.zeros(2 + 2 * n_parts, device=dev)
+        n_parts = 16         # the workgroups' sums go to pairs in cache lines of their own; the finish launch adds them up
+        sums = torch.zeros(32 * (1 + n_parts), device=dev)
         lse = torch.empty(M, device=dev)
         _ck(_lib.lib().bd_masked_ce_fwd_parts(_lib.ptr(lg), _lib.ptr(tg), _lib.ptr(ind), _lib.ptr(am), _lib.ptr(lse),
                                               _lib.ptr(sums), n_parts, M, V, _s()), "bd_masked_ce_fwd")

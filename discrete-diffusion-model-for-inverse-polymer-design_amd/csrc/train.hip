@@ -19,6 +19,7 @@ __device__ __forceinline__ float row_weight(const unsigned char* ind, const long
   return attn ? (float)attn[m] : 1.f;
 }
 
+constexpr int BD_CE_PART_STRIDE = 32;   // floats between the partial pairs of the sums buffer: one 128-byte line each
 constexpr int CE_ROWS = 32;   // rows per workgroup: one pair of same-address atomics per 32 rows
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits,
                                                      const long long* __restrict__ targets,
@@ -29,34 +30,54 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
   __shared__ float part[8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float lsum = 0.f, wsum = 0.f;
-  for (int i = wave; i < CE_ROWS; i += 4) {
-    const int row = blockIdx.x * CE_ROWS + i;
-    if (row >= M) break;
-    const float w = row_weight(ind, attn, row);
-    float lse = 0.f;
-    if (w != 0.f) {
-      const float* x = logits + (size_t)row * V;
-      float mx = -INFINITY, se = 0.f;
-      if (V <= 1024) {          // the row in registers: one pass over memory
-        float r[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) r[k] = (lane + 64 * k) < V ? x[lane + 64 * k] : -INFINITY;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) mx = fmaxf(mx, r[k]);
-        mx = bd_wave_max(mx);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) se += __expf(r[k] - mx);     // exp(-inf) = 0 past the row
-      } else {
-        for (int v = lane; v < V; v += 64) mx = fmaxf(mx, x[v]);
-        mx = bd_wave_max(mx);
-        for (int v = lane; v < V; v += 64) se += __expf(x[v] - mx);
-      }
-      se = bd_wave_sum(se);
-      lse = mx + __logf(se);
-      const float ce = lse - x[targets[row]];
-      lsum += ce * w;
-      wsum += w;
+  // The workgroup's rows with a weight are listed first (weights and targets fetched by 32 lanes at once), then dealt
+  // to the four waves in turn: a wave's rows are a chain of load - reduce - exp - reduce each, and the kernel lasts as
+  // long as its longest chain (rows taken in fixed places, one wave in a thousand met six live rows of eight).
+  __shared__ float sw[CE_ROWS];
+  __shared__ int st[CE_ROWS], srow[CE_ROWS], n_live;
+  const int base = blockIdx.x * CE_ROWS;
+  if (wave == 0) {
+    float w = 0.f;
+    int tg = 0;
+    const int row = base + lane;
+    if (lane < CE_ROWS && row < M) {
+      w = row_weight(ind, attn, row);
+      if (w != 0.f) tg = (int)targets[row];
+      else lse_out[row] = 0.f;
     }
+    const unsigned long long live = __ballot(w != 0.f);
+    if (w != 0.f) {
+      const int pos = __popcll(live & ((1ull << lane) - 1ull));
+      sw[pos] = w; st[pos] = tg; srow[pos] = row;
+    }
+    if (lane == 0) n_live = __popcll(live);
+  }
+  __syncthreads();
+  const int nl = n_live;
+  for (int idx = wave; idx < nl; idx += 4) {
+    const int row = srow[idx];
+    const float w = sw[idx];
+    const float* x = logits + (size_t)row * V;
+    const float xt = x[st[idx]];
+    float mx = -INFINITY, se = 0.f;
+    if (V <= 1024) {          // the row in registers: one pass over memory
+      float r[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) r[q] = (lane + 64 * q) < V ? x[lane + 64 * q] : -INFINITY;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) mx = fmaxf(mx, r[q]);
+      mx = bd_wave_max(mx);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) se += __expf(r[q] - mx);     // exp(-inf) = 0 past the row
+    } else {
+      for (int v = lane; v < V; v += 64) mx = fmaxf(mx, x[v]);
+      mx = bd_wave_max(mx);
+      for (int v = lane; v < V; v += 64) se += __expf(x[v] - mx);
+    }
+    se = bd_wave_sum(se);
+    const float lse = mx + __logf(se);
+    lsum += (lse - xt) * w;
+    wsum += w;
     if (lane == 0) lse_out[row] = lse;
   }
   if (lane == 0) { part[wave] = lsum; part[4 + wave] = wsum; }
@@ -64,9 +85,10 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
   if (threadIdx.x == 0) {
     const float a = (part[0] + part[1]) + (part[2] + part[3]);
     const float b = (part[4] + part[5]) + (part[6] + part[7]);
-    // n_parts > 0: the pair goes to one of n_parts pairs behind sums[0..1] (bd_masked_ce_finish adds them up): atomics
-    // on one address retire one after another, and every workgroup ends with this pair
-    float* dst = n_parts > 0 ? sums + 2 + 2 * (blockIdx.x % n_parts) : sums;
+    // n_parts > 0: the pair goes to one of n_parts pairs behind sums[0..1], each in a cache line of its own
+    // (bd_masked_ce_finish adds them up): atomics on one LINE retire one after another, about 75 ns each, and every
+    // workgroup ends with this pair
+    float* dst = n_parts > 0 ? sums + BD_CE_PART_STRIDE * (1 + blockIdx.x % n_parts) : sums;
     if (b != 0.f) { atomicAdd(&dst[0], a); atomicAdd(&dst[1], b); }
   }
 }
@@ -75,7 +97,7 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
 __global__ void ce_finish_kernel(float* __restrict__ sums, float* __restrict__ loss, int n_parts) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     float a = sums[0], b = sums[1];
-    for (int k = 0; k < n_parts; ++k) { a += sums[2 + 2 * k]; b += sums[3 + 2 * k]; }
+    for (int k = 0; k < n_parts; ++k) { a += sums[BD_CE_PART_STRIDE * (1 + k)]; b += sums[BD_CE_PART_STRIDE * (1 + k) + 1]; }
     if (n_parts > 0) { sums[0] = a; sums[1] = b; }      // the backward pass reads the totals here
     loss[0] = b > 0.f ? a / b : 0.f;
   }

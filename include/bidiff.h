@@ -306,9 +306,9 @@ int bd_gemm_bf16_drop(const void* A, const void* W, const float* bias, void* out
  * replaces DiscreteMaskingDiffusion._compute_loss, src/model/diffusion.py:169-209, and its autograd. */
 int bd_masked_ce_fwd(const float* logits, const long long* targets, const unsigned char* indicator,
                      const long long* attention_mask, float* lse, float* sums, int M, int V, void* stream);
-/* bd_masked_ce_fwd with the two sums spread over n_parts pairs: sums is [2 + 2 * n_parts] floats, zeroed by the caller;
- * workgroup w adds to sums[2 + 2 (w % n_parts)] and the float behind it (one address then takes n_parts times fewer
- * atomics, which retire one after another). bd_masked_ce_finish adds the pairs into sums[0] and sums[1], where
+/* bd_masked_ce_fwd with the two sums spread over n_parts pairs, each in a 128-byte line of its own: sums is
+ * [32 * (1 + n_parts)] floats, zeroed by the caller; workgroup w adds to sums[32 * (1 + w % n_parts)] and the float
+ * behind it (a cache line then takes n_parts times fewer atomics, which retire one after another). bd_masked_ce_finish adds the pairs into sums[0] and sums[1], where
  * bd_masked_ce_bwd reads them, and writes loss[0] = sums[0] / sums[1], exactly 0 when sums[1] == 0 (the reference
  * returns a zero that is still attached to the graph when no position is both masked and attended,
  * src/model/diffusion.py:203-205). n_parts = 0: sums is the plain pair of bd_masked_ce_fwd. */

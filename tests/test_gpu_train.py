@@ -733,7 +733,8 @@ def test_masked_ce_finish_divides_and_keeps_the_empty_case_at_zero(gpu_device):
         assert lib.bd_masked_ce_finish(_lib.ptr(s_), _lib.ptr(out), 0, _lib.stream_handle()) == 0
         assert float(out) == want
     # pairs behind the totals: added into sums[0..1], where the backward pass reads them
-    s_ = torch.tensor([0.0, 0.0, 1.0, 2.0, 5.0, 2.0, 0.0, 0.0], device=dev)
+    s_ = torch.zeros(32 * 4, device=dev)
+    s_[32], s_[33], s_[64], s_[65] = 1.0, 2.0, 5.0, 2.0
     out = torch.full((), -1.0, device=dev)
     assert lib.bd_masked_ce_finish(_lib.ptr(s_), _lib.ptr(out), 3, _lib.stream_handle()) == 0
     assert float(out) == 1.5 and s_[:2].tolist() == [6.0, 4.0]

@@ -32,14 +32,14 @@ for B in (4096, 262144):
 # masked CE at the training shape: rows with weight 0 are never read (about 30 % of the rows are non-pad, ~half of them masked)
 M, V = 32768, 803
 lg = torch.randn(M, V, device=dev); tg = torch.randint(0, V, (M,), device=dev)
-indm = (torch.rand(M, device=dev) < 0.16).to(torch.uint8); lse = torch.empty(M, device=dev); sums = torch.zeros(2 + 16, device=dev)
+indm = (torch.rand(M, device=dev) < 0.16).to(torch.uint8); lse = torch.empty(M, device=dev); sums = torch.zeros(32 * 17, device=dev)
 nz = int(indm.sum().item())
-timeit("ce_fwd_kernel M=32768 V=803 (16% rows live)", lambda: lib.bd_masked_ce_fwd_parts(P(lg), P(tg), P(indm), None, P(lse), P(sums), 8, M, V, s()),
+timeit("ce_fwd_kernel M=32768 V=803 (16% rows live)", lambda: lib.bd_masked_ce_fwd_parts(P(lg), P(tg), P(indm), None, P(lse), P(sums), 16, M, V, s()),
        nz * V * 4 + M * (8 + 1 + 4), note="reads only live rows")
 indf = torch.ones(M, dtype=torch.uint8, device=dev)
-timeit("ce_fwd_kernel M=32768 V=803 (all rows live)", lambda: lib.bd_masked_ce_fwd_parts(P(lg), P(tg), P(indf), None, P(lse), P(sums), 8, M, V, s()),
-       M * V * 4 + M * 13, note="sums into eight pairs; into one pair the 1024 workgroups' atomics queue on two addresses")
-lib.bd_masked_ce_finish(P(sums), P(torch.empty(1, device=dev)), 8, s())
+timeit("ce_fwd_kernel M=32768 V=803 (all rows live)", lambda: lib.bd_masked_ce_fwd_parts(P(lg), P(tg), P(indf), None, P(lse), P(sums), 16, M, V, s()),
+       M * V * 4 + M * 13, note="sums into 16 pairs in cache lines of their own")
+lib.bd_masked_ce_finish(P(sums), P(torch.empty(1, device=dev)), 16, s())
 g1 = torch.ones(1, device=dev); dl = torch.empty_like(lg)
 timeit("ce_bwd_kernel M=32768 V=803 (all rows live)", lambda: lib.bd_masked_ce_bwd(P(lg), P(tg), P(indf), None, P(lse), P(sums), P(g1), P(dl), M, V, s()),
        2 * M * V * 4 + M * 17)
