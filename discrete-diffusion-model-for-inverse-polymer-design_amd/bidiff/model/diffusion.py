@@ -61,6 +61,16 @@ class _Outputs(dict):
         self._build_all()
         return dict.__repr__(self)
 
+    def __eq__(self, other):
+        self._build_all()
+        return dict.__eq__(self, other)
+
+    def __ne__(self, other):
+        self._build_all()
+        return dict.__ne__(self, other)
+
+    __hash__ = None
+
 
 class DiscreteMaskingDiffusion(nn.Module):
     def __init__(

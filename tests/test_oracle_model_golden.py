@@ -146,3 +146,5 @@ def test_forward_result_dict_builds_deferred_entries_on_first_access():
     assert sorted(k for k in out3) == ["logits", "loss"] and "L" in out3.values()
     with pytest.raises(KeyError):
         out3["missing"]
+    assert _Outputs({"loss": 1.0}, {"logits": build}) == {"loss": 1.0, "logits": "L"}
+    assert dict(_Outputs({"loss": 1.0}, {"logits": build})) == {"loss": 1.0, "logits": "L"}
