@@ -775,3 +775,31 @@ def test_layernorm_bwd_parts_sum_to_the_single_copy_result(gpu_device, n_parts):
     assert float((dst[0][0] - dg1).abs().max()) < 1e-4 * scale and float((dst[0][1] - db1).abs().max()) < 1e-4 * scale
     assert float((dst[1][0] - (dg1 - dg0)).abs().max()) < 1e-4 * scale
     assert float(parts.abs().max()) == 0.0
+
+
+def test_partial_sum_entry_points_reject_bad_arguments(gpu_device):
+    """The entry points with partial-sum copies refuse copy counts outside 1..64 (0..64 for the cross-entropy, where 0
+    is the plain pair) and null buffers, with a message, instead of launching."""
+    dev = gpu_device
+    lib = _lib.lib()
+    P, st_ = _lib.ptr, _lib.stream_handle
+    M, d, V = 64, 128, 40
+    dy = torch.zeros(M, d, device=dev, dtype=torch.bfloat16); x = torch.zeros(M, d, device=dev)
+    stats = torch.ones(M, 2, device=dev); gm = torch.ones(d, device=dev); dx = torch.zeros(M, d, device=dev)
+    parts = torch.zeros(2, 2, d, device=dev)
+    for n_parts in (0, 65):
+        assert lib.bd_layernorm_bwd_parts(P(dy), P(x), P(stats), P(gm), None, P(dx), P(parts), n_parts, M, d, None, None, 0, st_()) != 0
+        assert b"parts" in lib.bd_last_error()
+    assert lib.bd_layernorm_bwd_parts(P(dy), P(x), P(stats), P(gm), None, P(dx), None, 2, M, d, None, None, 0, st_()) != 0
+    assert lib.bd_layernorm_parts_finish(None, 1, 2, d, st_()) != 0
+    lg = torch.zeros(M, V, device=dev); tg = torch.zeros(M, dtype=torch.long, device=dev)
+    ind = torch.ones(M, dtype=torch.uint8, device=dev); lse = torch.zeros(M, device=dev); sums = torch.zeros(32 * 3, device=dev)
+    assert lib.bd_masked_ce_fwd_parts(P(lg), P(tg), P(ind), None, P(lse), P(sums), 65, M, V, st_()) != 0
+    assert lib.bd_masked_ce_fwd_parts(P(lg), P(tg), P(ind), None, P(lse), None, 2, M, V, st_()) != 0
+    assert lib.bd_masked_ce_finish(P(sums), None, 2, st_()) != 0
+    assert lib.bd_pack_targets(P(tg), P(ind), None, None, M, P(tg), P(ind), st_()) != 0
+    # and the good calls still go through
+    assert lib.bd_masked_ce_fwd_parts(P(lg), P(tg), P(ind), None, P(lse), P(sums), 2, M, V, st_()) == 0
+    loss = torch.zeros((), device=dev)
+    assert lib.bd_masked_ce_finish(P(sums), P(loss), 2, st_()) == 0
+    assert abs(float(loss) - math.log(V)) < 1e-4 and abs(float(sums[1]) - M) < 1e-3
