@@ -1,0 +1,102 @@
+"""Edges of the sampler classes' public API on the GPU: the smallest and the longest sequences, more reverse
+steps than masked positions, ragged last batches, and the argument errors the reference raises
+(Bi_Diffusion_SMILES/src/sampling/sampler.py:42-43, :749-750, :835-836)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+from tests.test_gpu_sampler_e2e import build_model, replay
+from oracle import sampler_ref as ora
+
+pytestmark = pytest.mark.gpu
+
+
+def _sampler(variant, dev, T, **kw):
+    _, tok = H.make_sampler(variant)
+    model = build_model(tok, dev, T)
+    smp, _ = H.make_sampler(variant, model=model, num_steps=T, device=str(dev), **kw)
+    return smp, tok
+
+
+@pytest.mark.parametrize("variant", ["smiles", "selfies", "group", "bpe"])
+@pytest.mark.parametrize("B,L", [(1, 2), (1, 3), (3, 5), (1, 128)])
+def test_smallest_batches_and_sequences(gpu_device, variant, B, L):
+    """One sequence, and sequences with no (L = 2: BOS, EOS), one and three free positions, every step replayed by
+    the oracle. T = 6 is more steps than free positions: the late steps find nothing to draw."""
+    T = 6
+    smp, tok = _sampler(variant, gpu_device, T)
+    smp._core.seed = 5
+    smp._core.record = []
+    ids, strings = smp.sample(B, L, show_progress=False)
+    assert ids.shape == (B, L) and ids.dtype == torch.long and len(strings) == B
+    out = ids.cpu().numpy()
+    assert (out != tok.mask_token_id).all()
+    assert (out[:, 0] == tok.bos_token_id).all() and (out[:, -1] == tok.eos_token_id).all()
+    tb = H.oracle_tables(smp)
+    rec = smp._core.record
+    assert len(rec) == T
+    fixed = (rec[0]["ids_before"].numpy() != tb.mask_id).astype(np.uint8) if variant in ("smiles", "bpe") else None
+    o, _ = replay(rec, tb, T, L, 1.0, True, fixed)
+    of = ora.sample_fixup(tb, o["ids"], o["logits"], natural_eos=False, attn=o["attn"], has_eos=o["has_eos"])
+    np.testing.assert_array_equal(out, of["ids"])
+
+
+@pytest.mark.parametrize("variant,L", [("smiles", 200), ("selfies", 129), ("smiles", 512)])
+def test_sequences_longer_than_the_fused_kernels_take(gpu_device, variant, L):
+    """L > 128 leaves the single-launch forward for the per-operation kernels (LayerNorm, tiled GEMMs, stand-alone
+    attention); L = 512 is the position table's last row. Steps replayed by the oracle, repairs included."""
+    T, B = 5, 6
+    smp, tok = _sampler(variant, gpu_device, T)
+    smp._core.seed = 17
+    smp._core.record = []
+    ids, strings = smp.sample(B, L, show_progress=False)
+    out = ids.cpu().numpy()
+    assert out.shape == (B, L) and (out != tok.mask_token_id).all()
+    tb = H.oracle_tables(smp)
+    rec = smp._core.record
+    fixed = (rec[0]["ids_before"].numpy() != tb.mask_id).astype(np.uint8) if variant == "smiles" else None
+    o, _ = replay(rec, tb, T, L, 1.0, True, fixed)
+    of = ora.sample_fixup(tb, o["ids"], o["logits"], natural_eos=False, attn=o["attn"], has_eos=o["has_eos"])
+    np.testing.assert_array_equal(out, of["ids"])
+    with pytest.raises((RuntimeError, ValueError, IndexError)):
+        smp.sample(2, 513, show_progress=False)          # beyond max_position_embeddings, as the reference's embedding
+
+
+def test_ragged_last_batch_equals_one_batch(gpu_device):
+    """sample_batch(10, batch_size=4) draws batches of 4, 4 and 2; numbered globally they are the rows of sample(10)."""
+    T, L = 6, 24
+    smp, tok = _sampler("smiles", gpu_device, T)
+    smp._core.seed = 9
+    whole, s_whole = smp.sample(10, L, show_progress=False)
+    parts, s_parts = smp.sample_batch(10, L, batch_size=4, show_progress=False)
+    assert [p.shape[0] for p in parts] == [4, 4, 2]
+    assert torch.equal(torch.cat(parts), whole) and s_parts == s_whole
+    lengths = [2, 24, 3, 7, 24, 11, 5]
+    parts, s_parts = smp.sample_batch(7, L, batch_size=3, show_progress=False, lengths=lengths)
+    assert [tuple(p.shape) for p in parts] == [(3, 24), (3, 24), (1, 5)]      # each batch as long as its longest row
+    whole, s_whole = smp.sample_with_lengths(lengths, max_length=L, show_progress=False)
+    for i, ln in enumerate(lengths):
+        row = parts[i // 3][i % 3]
+        assert torch.equal(row[:ln], whole[i, :ln])
+        assert (row[ln:] == tok.pad_token_id).all()
+    assert s_parts == s_whole
+    none_ids, none_strings = smp.sample_batch(0, L, batch_size=4, show_progress=False)
+    assert none_ids == [] and none_strings == []
+    empty, es = smp.sample_with_lengths([], show_progress=False)
+    assert empty.numel() == 0 and es == []
+
+
+def test_argument_errors_of_the_reference(gpu_device):
+    smp, tok = _sampler("smiles", gpu_device, 4)
+    with pytest.raises(ValueError, match="lengths must match num_samples"):
+        smp.sample_batch(3, 16, lengths=[5, 6], show_progress=False)
+    with pytest.raises(ValueError, match="smaller than required"):
+        smp.sample_with_lengths([5, 40], max_length=32, show_progress=False)
+    for variant in ("smiles", "selfies", "group"):
+        with pytest.raises(ValueError, match="temperature"):
+            H.make_sampler(variant, model=smp.diffusion_model, temperature=0.0, device=str(gpu_device))
+    # lengths below 2 are raised to 2 (BOS + EOS), as the reference's max(2, int(length))
+    ids, strings = smp.sample_with_lengths([0, 1, 2], show_progress=False)
+    assert ids.shape == (3, 2) and (ids[:, 0] == tok.bos_token_id).all() and (ids[:, 1] == tok.eos_token_id).all()
+    assert strings == ["", "", ""]
