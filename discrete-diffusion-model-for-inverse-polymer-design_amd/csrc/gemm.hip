@@ -400,9 +400,33 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
 typedef __attribute__((address_space(1))) void g256_glb;
 typedef __attribute__((address_space(3))) void g256_lds;
 constexpr int G256_STAGE = 32768, G256_PART = 16384;   // four stages of BK = 32
+// The same kernel on a 128 x 128 tile (T = 2: waves of 64 x 64) with an EIGHT-stage ring (16 KB per stage, seven
+// stages = 224 k-values in flight) serves the products with few tiles and a long K (the training step's N = 384,
+// K = 1152 / 1536 products: 240 tiles for 256 CUs). There the register-staged 128 x 128 kernel above has one k-step
+// in flight and pays a memory latency per step (0.65 us per 64 k-values, against 0.2 us of MFMAs).
+constexpr int G128_STAGES = 8, G128_STAGE = 16384;
 
-template <int EPI, bool DROP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm256_kernel(GemmArgs p) {
+template <int NP, int MAXL>
+__device__ __forceinline__ void g256_stage_ready(int later_stages) {
+  // this wave's pieces of the stage have landed, `later_stages` younger stages (NP pieces each) may stay in flight
+  if (MAXL >= 6 && later_stages >= 6) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(6 * NP) : "memory");
+  else if (MAXL >= 5 && later_stages == 5) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(5 * NP) : "memory");
+  else if (MAXL >= 4 && later_stages == 4) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * NP) : "memory");
+  else if (MAXL >= 3 && later_stages == 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * NP) : "memory");
+  else if (later_stages >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NP) : "memory");
+  else if (later_stages == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NP) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// T = 32-row operand tiles per wave and side (4: the 256 x 256 tile described above, 2: 128 x 128), NS = ring stages
+template <int EPI, bool DROP, int T, int NS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, T == 4 ? 1 : 2))) void gemm256_kernel(GemmArgs p) {
+  constexpr int TILE = 64 * T;                 // rows of either operand per workgroup
+  constexpr int PART = TILE * 64;              // bytes of one operand's rows in a stage (BK = 32)
+  constexpr int STAGE = 2 * PART;
+  constexpr int NP = 2 * T;                    // pieces a wave moves per stage (T weight + T activation)
+  constexpr int NM = T * T;                    // MFMAs per k16 index and wave
+  static_assert((NS & (NS - 1)) == 0 && NS >= 4 && NS <= 8 && 2 * T <= NM + 0 * NP, "unsupported ring / tile");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem256[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -424,28 +448,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // Tiles in groups of 8 tile rows, column by column inside a group: the 32 workgroups that an XCD runs at a time
   // (consecutive logical tiles) then cover 8 x 4 tiles and share 12 operand panels in their L2 instead of the 33
   // of a 1 x 32 strip.
-  const int tiles_n = p.Npad >> 8, tiles_m = (p.M + 255) >> 8;
+  const int tiles_n = p.Npad / TILE, tiles_m = (p.M + TILE - 1) / TILE;
   const int per_group = 8 * tiles_n, group = tile / per_group;
   const int rows_here = min(tiles_m - 8 * group, 8);
   const int in_group = tile - group * per_group;
-  const int m0 = (8 * group + in_group % rows_here) * 256, n0 = (in_group / rows_here) * 256;
+  const int m0 = (8 * group + in_group % rows_here) * TILE, n0 = (in_group / rows_here) * TILE;
   const int K = p.K, nk = K / 32;
 
-  // Four stages of BK = 32 (32 KB each: 256 weight rows and 256 activation rows x 64 B), so that two to three stages
-  // are in flight at any time: with two stages of BK = 64 every k-step began with nothing in flight (the whole next
+  // NS stages of BK = 32 (TILE weight rows and TILE activation rows x 64 B each), NS - 2 to NS - 1 of them in flight
+  // at any time: with two stages of BK = 64 every k-step began with nothing in flight (the whole next
   // stage is issued and awaited inside one step), and the CU's ingest path idled while the queue refilled.
   // DMA: a 1-KiB piece = 16 operand rows x 64 B (one 64-byte memory request per row). Lane i lands at byte 16 i of
   // the piece: row i / 4, 16-byte slot i % 4, and fetches the row's k-chunk (slot ^ ((row >> 2) & 3)), so that the
   // MFMA operand reads below (32 rows x one k-chunk) cover every bank once per 16 lanes. LDS row rho of a 32-row
-  // weight tile holds weight row n0 + 32 tile + nperm(rho). Wave w moves pieces 4 w .. 4 w + 3 of either part.
+  // weight tile holds weight row n0 + 32 tile + nperm(rho). Wave w moves pieces T w .. T w + T - 1 of either part.
   // A piece costs three instructions: M0 = LDS destination, then the load with a scalar base (the tile's rows at
   // this k-step) and one 32-bit lane offset per piece number. (The builtin with a per-lane 64-bit pointer makes the
   // compiler emit 64-bit vector adds per piece: 57 cycles of issue per piece instead of 20, on a wave whose SIMD has
   // no other wave to run.)
-  unsigned voffw[4], voffa[4];
+  unsigned voffw[T], voffa[T];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int row = 16 * (4 * wave + t) + (lane >> 2);         // 0 .. 255 inside the part
+  for (int t = 0; t < T; ++t) {
+    const int row = 16 * (T * wave + t) + (lane >> 2);         // 0 .. TILE - 1 inside the part
     const int rho = row & 31, tl = row >> 5;
     const int chunk = (lane & 3) ^ ((rho >> 2) & 3);
     const int np = 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3);
@@ -457,108 +481,103 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   const unsigned char* const wtile = (const unsigned char*)(p.W + (size_t)n0 * K);
   const unsigned char* const atile = (const unsigned char*)(p.A + (size_t)m0 * K);
-  const unsigned ldsw = (unsigned)(size_t)(g256_lds*)smem256 + wave * 4096;
-  // piece i of stage s: i < 4 weight rows, else activation rows
+  const unsigned ldsw = (unsigned)(size_t)(g256_lds*)smem256 + wave * (T * 1024);
+  // piece i of stage s: i < T weight rows, else activation rows
   auto piece = [&](int s, int i) {
-    const unsigned st = ldsw + (s & 3) * G256_STAGE;
-    const unsigned char* src = (i < 4 ? wtile : atile) + (size_t)s * 64;
+    const unsigned st = ldsw + (s & (NS - 1)) * STAGE;
+    const unsigned char* src = (i < T ? wtile : atile) + (size_t)s * 64;
     asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"
-                 ::"s"(st), "i"((i & 3) * 1024 + (i < 4 ? 0 : G256_PART)), "v"(i < 4 ? voffw[i & 3] : voffa[i & 3]), "s"(src)
+                 ::"s"(st), "i"((i % T) * 1024 + (i < T ? 0 : PART)), "v"(i < T ? voffw[i % T] : voffa[i % T]), "s"(src)
                  : "memory", "m0", "scc");
   };
 
-  f32x16 acc[4][4];
+  f32x16 acc[T][T];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < T; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < T; ++j) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-      asm volatile("" : "+a"(acc[i][j]));
+      if (T == 4) asm volatile("" : "+a"(acc[i][j]));
     }
 
-  // operand addresses of this wave inside a stage: W tiles 4 wn + j, A tiles 4 wm + j (2 KiB each: 32 rows x 64 B);
+  // operand addresses of this wave inside a stage: W tiles T wn + j, A tiles T wm + j (2 KiB each: 32 rows x 64 B);
   // lane (r, kh) reads row r, k-chunk 2 q + kh (q = 0, 1), which sits in slot (2 q + kh) ^ ((r >> 2) & 3)
   const unsigned lds0 = (unsigned)(size_t)(g256_lds*)smem256 + r * 64;
-  const unsigned wbase = lds0 + (4 * wn) * 2048, abase = lds0 + G256_PART + (4 * wm) * 2048;
+  const unsigned wbase = lds0 + (T * wn) * 2048, abase = lds0 + PART + (T * wm) * 2048;
   unsigned qoff[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) qoff[q] = (unsigned)(((2 * q + kh) ^ ((r >> 2) & 3)) * 16);
 
-  bf16x8 fw[2][4], fa[2][4];
-  // one operand read of stage s: i < 4 weight tile i, else activation tile i - 4, k16 index q, into register set q
+  bf16x8 fw[2][T], fa[2][T];
+  // one operand read of stage s: i < T weight tile i, else activation tile i - T, k16 index q, into register set q
   auto read1 = [&](int s, int q, int i) {
-    const unsigned so = (s & 3) * G256_STAGE;
-    if (i < 4)
-      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fw[q][i & 3]) : "v"(wbase + so + qoff[q]), "i"((i & 3) * 2048));
+    const unsigned so = (s & (NS - 1)) * STAGE;
+    if (i < T)
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fw[q][i % T]) : "v"(wbase + so + qoff[q]), "i"((i % T) * 2048));
     else
-      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[q][i & 3]) : "v"(abase + so + qoff[q]), "i"((i & 3) * 2048));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[q][i % T]) : "v"(abase + so + qoff[q]), "i"((i % T) * 2048));
   };
   auto wait_reads = [&](int q) {      // every register written by the reads of set q passes through this wait
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(fw[q][0]), "+v"(fw[q][1]), "+v"(fw[q][2]), "+v"(fw[q][3]), "+v"(fa[q][0]), "+v"(fa[q][1]),
-                   "+v"(fa[q][2]), "+v"(fa[q][3]));
-  };
-  // wait until this wave's pieces of stage s have landed (pieces issued later may stay in flight: 8 per stage, loads
-  // return in order), then the barrier: every wave's pieces of stage s are in LDS, and nobody reads stage s - 2 or
-  // older any more
-  auto stage_ready = [&](int later_stages) {
-    if (later_stages >= 2) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-    else if (later_stages == 1) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (T == 4)
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(fw[q][0]), "+v"(fw[q][1]), "+v"(fw[q][2]), "+v"(fw[q][3]), "+v"(fa[q][0]), "+v"(fa[q][1]),
+                     "+v"(fa[q][2]), "+v"(fa[q][3]));
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fw[q][0]), "+v"(fw[q][1]), "+v"(fa[q][0]), "+v"(fa[q][1]));
   };
 
-  // prologue: stages 0, 1, 2 on their way; stage 0 landed; its first operands read
+  // prologue: stages 0 .. NS - 2 on their way; stage 0 landed; its first operands read
 #pragma unroll
-  for (int st = 0; st < 3; ++st)
+  for (int st = 0; st < NS - 1; ++st)
     if (st < nk) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) piece(st, i);
+      for (int i = 0; i < NP; ++i) piece(st, i);
     }
-  stage_ready(min(nk - 1, 2));
+  g256_stage_ready<NP, NS - 2>(min(nk - 1, NS - 2));
 #pragma unroll
-  for (int i = 0; i < 8; ++i) read1(0, 0, i);
+  for (int i = 0; i < 2 * T; ++i) read1(0, 0, i);
 
   // Step s: MFMAs of k16 index 0 with the reads of index 1 between them; then stage s + 1 must have landed (barrier in
   // the MIDDLE of the step, so that its first reads can go out between the MFMAs of index 1 and no step begins with
-  // an exposed LDS latency); then the MFMAs of index 1 with those reads and the pieces of stage s + 3 between them
+  // an exposed LDS latency); then the MFMAs of index 1 with those reads and the pieces of stage s + NS - 1 between them
   // (its buffer held stage s - 1, which every wave has left behind when it reaches this step's barrier).
   // One wave per SIMD issues in order: whatever is not placed between two MFMAs adds to the step.
   for (int s = 0; s < nk; ++s) {
     wait_reads(0);
 #pragma unroll
-    for (int jn = 0; jn < 4; ++jn)
+    for (int jn = 0; jn < T; ++jn)
 #pragma unroll
-      for (int jm = 0; jm < 4; ++jm) {
-        const int i = 4 * jn + jm;
+      for (int jm = 0; jm < T; ++jm) {
+        const int i = T * jn + jm;
         acc[jn][jm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[0][jn], fa[0][jm], acc[jn][jm], 0, 0, 0);
-        if (i < 8) read1(s, 1, i);
+        if (i < 2 * T) read1(s, 1, i);
         __builtin_amdgcn_sched_barrier(0);
       }
-    const bool next = s + 1 < nk, issue = s + 3 < nk;
-    if (next) stage_ready(min(nk - 2 - s, 1));      // stage s + 2 (if any) may still be in flight
+    const bool next = s + 1 < nk, issue = s + NS - 1 < nk;
+    if (next) g256_stage_ready<NP, NS - 3>(min(nk - 2 - s, NS - 3));      // younger stages may still be in flight
     wait_reads(1);
 #pragma unroll
-    for (int jn = 0; jn < 4; ++jn)
+    for (int jn = 0; jn < T; ++jn)
 #pragma unroll
-      for (int jm = 0; jm < 4; ++jm) {
-        const int i = 4 * jn + jm;
+      for (int jm = 0; jm < T; ++jm) {
+        const int i = T * jn + jm;
         acc[jn][jm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[1][jn], fa[1][jm], acc[jn][jm], 0, 0, 0);
-        if (i < 8 && next) read1(s + 1, 0, i);
-        if (i >= 8 && issue) piece(s + 3, i - 8);
+        if (i < 2 * T && next) read1(s + 1, 0, i);
+        if (i >= NM - NP && issue) piece(s + NS - 1, i - (NM - NP));
         __builtin_amdgcn_sched_barrier(0);
       }
   }
 
-  // ---- epilogue: tile (jn, jm): lane holds row m = m0 + 128 wm + 32 jm + r, columns nb .. nb + 15
+  // ---- epilogue: tile (jn, jm): lane holds row m = m0 + 32 T wm + 32 jm + r, columns nb .. nb + 15
 #pragma unroll
-  for (int jn = 0; jn < 4; ++jn) {
-    const int nb = n0 + 128 * wn + 32 * jn + 16 * kh;
+  for (int jn = 0; jn < T; ++jn) {
+    const int nb = n0 + 32 * T * wn + 32 * jn + 16 * kh;
     float bv[16];
     load_bias16<EPI>(p, nb, bv);
 #pragma unroll
-    for (int jm = 0; jm < 4; ++jm) {
-      const int m = m0 + 128 * wm + 32 * jm + r;
+    for (int jm = 0; jm < T; ++jm) {
+      const int m = m0 + 32 * T * wm + 32 * jm + r;
       if (m >= p.M) continue;
       float v[16];
 #pragma unroll
@@ -590,14 +609,25 @@ bool use_gemm256(const GemmArgs& a) {
   if (a.K < 768) return false;        // few k-steps: the 128 x 128 kernel with two workgroups per CU hides its epilogue better
   return (((long long)a.M + 255) / 256) * (a.Npad / 256) >= 128;
 }
+// the deep-ring 128 x 128 kernel: a long K on few tiles (at most about one per CU)
+bool use_gemm128_ring(const GemmArgs& a) {
+  static int mode = getenv("BD_GEMM128_RING") ? atoi(getenv("BD_GEMM128_RING")) : 1;
+  if (!mode || a.n_real != a.Npad || a.K % 32 != 0) return false;
+  if (mode == 2) return true;         // every shape (measurements)
+  return a.K >= 768 && a.n_tiles <= 320;
+}
 
 template <int EPI, bool DROP = false>
 int launch(const GemmArgs& a, hipStream_t s) {
   void* tok = bd_prof_on() ? bd_prof_begin(s) : nullptr;
   if (use_gemm256(a)) {
     const long long nt = (((long long)a.M + 255) / 256) * (a.Npad / 256);
-    BD_SET_MAX_LDS((gemm256_kernel<EPI, DROP>), 4 * G256_STAGE);
-    hipLaunchKernelGGL((gemm256_kernel<EPI, DROP>), dim3((unsigned)nt), dim3(256), 4 * G256_STAGE, s, a);
+    BD_SET_MAX_LDS((gemm256_kernel<EPI, DROP, 4, 4>), 4 * G256_STAGE);
+    hipLaunchKernelGGL((gemm256_kernel<EPI, DROP, 4, 4>), dim3((unsigned)nt), dim3(256), 4 * G256_STAGE, s, a);
+  } else if (use_gemm128_ring(a)) {
+    BD_SET_MAX_LDS((gemm256_kernel<EPI, DROP, 2, G128_STAGES>), G128_STAGES * G128_STAGE);
+    hipLaunchKernelGGL((gemm256_kernel<EPI, DROP, 2, G128_STAGES>), dim3((unsigned)a.n_tiles), dim3(256),
+                       G128_STAGES * G128_STAGE, s, a);
   } else {
     hipLaunchKernelGGL((gemm_bf16_kernel<EPI, DROP>), dim3(persistent_grid(a.n_tiles)), dim3(256), 0, s, a);
   }
