@@ -371,7 +371,7 @@ def main():
                     help="sequences in the CPU baseline (256 = BASELINE configuration 1; 0 = skip)")
     ap.add_argument("--cpu-train-steps", type=int, default=2, help="timed CPU training steps (0 = skip)")
     ap.add_argument("--no-constraints", action="store_true")
-    ap.add_argument("--train-steps", type=int, default=20, help="timed training steps (0 = skip the training leg)")
+    ap.add_argument("--train-steps", type=int, default=50, help="timed training steps after 10 warm-up steps (0 = skip the training leg)")
     ap.add_argument("--no-configs", action="store_true", help="skip the SELFIES / Group SELFIES / stress-backbone records")
     ap.add_argument("--c5-batch", type=int, default=128)
     args = ap.parse_args()
@@ -447,7 +447,7 @@ def main():
     train = None
     if args.train_steps > 0:
         try:
-            train = train_bench(dev, rank, world, args.train_steps, 5, args.cpu_train_steps, threads)
+            train = train_bench(dev, rank, world, args.train_steps, 10, args.cpu_train_steps, threads)
         except Exception as exc:      # the sampling line (the headline metric) is still reported
             train = {"error": f"{type(exc).__name__}: {exc}"}
     configs = None
