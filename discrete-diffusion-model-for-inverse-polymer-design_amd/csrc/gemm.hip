@@ -426,7 +426,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, T == 4 ?
   constexpr int STAGE = 2 * PART;
   constexpr int NP = 2 * T;                    // pieces a wave moves per stage (T weight + T activation)
   constexpr int NM = T * T;                    // MFMAs per k16 index and wave
-  static_assert((NS & (NS - 1)) == 0 && NS >= 4 && NS <= 8 && 2 * T <= NM + 0 * NP, "unsupported ring / tile");
+  static_assert((NS & (NS - 1)) == 0 && NS >= 4 && NS <= 8, "ring depth: a power of two, 4 .. 8 (buffer index by mask, vmcnt <= 63)");
+  static_assert(NP <= NM, "the operand reads and the pieces of a step are placed one per MFMA");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem256[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
