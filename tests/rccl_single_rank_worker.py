@@ -1,4 +1,4 @@
-"""Child process of tests/test_gpu_rccl.py: the training step's gradient exchange and the bench's collectives over
+"""Child process of tests/test_zy_rccl_single_rank.py: the training step's gradient exchange and the bench's collectives over
 the RCCL backend with ONE rank on cuda:0.
 
 A one-GPU box cannot host two RCCL ranks, so the transport between GPUs is not what this covers. It covers what
