@@ -1,12 +1,13 @@
-"""Child process of tests/test_zy_rccl_single_rank.py: the training step's gradient exchange and the bench's collectives over
-the RCCL backend with ONE rank on cuda:0.
+"""Child process of tests/test_zy_rccl_single_rank.py: the training step's gradient exchange and the bench's
+collectives over the RCCL backend with ONE rank on cuda:0.
 
 A one-GPU box cannot host two RCCL ranks, so the transport between GPUs is not what this covers. It covers what
 the library's side of a data-parallel step can get wrong on real hardware: the asynchronous all-reduce of the
 flat buffer's tail is started by a hook INSIDE the backward pass, on the stream that completes those gradients,
 while the lower layers' kernels keep writing the head of the same buffer on other streams; finish() reduces the
 head and makes the optimizer's stream wait for both collectives. With one rank every sum is the identity, so the
-exchanged gradients must equal the ones of a step without any exchange, bit for bit."""
+exchanged gradients must equal the ones of a step without any exchange (to rounding: they are sums of float
+atomics, so two runs of the same step differ in the last bits)."""
 import os
 import sys
 
