@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, T == 4 ?
   // Tiles in groups of 8 tile rows, column by column inside a group: the 32 workgroups that an XCD runs at a time
   // (consecutive logical tiles) then cover 8 x 4 tiles and share 12 operand panels in their L2 instead of the 33
   // of a 1 x 32 strip.
-  const int tiles_n = p.Npad / TILE, tiles_m = (p.M + TILE - 1) / TILE;
+  const int tiles_n = (p.Npad + TILE - 1) / TILE, tiles_m = (p.M + TILE - 1) / TILE;
   const int per_group = 8 * tiles_n, group = tile / per_group;
   const int rows_here = min(tiles_m - 8 * group, 8);
   const int in_group = tile - group * per_group;
@@ -474,7 +474,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, T == 4 ?
     const int rho = row & 31, tl = row >> 5;
     const int chunk = (lane & 3) ^ ((rho >> 2) & 3);
     const int np = 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3);
-    voffw[t] = (unsigned)(((32 * tl + np) * K + 8 * chunk) * 2);
+    // Npad is a multiple of 128: the last 256-column tile may be half empty; its missing weight rows read the
+    // last row instead (finite values, results never stored)
+    const int wr = min(32 * tl + np, p.Npad - 1 - n0);
+    voffw[t] = (unsigned)((wr * K + 8 * chunk) * 2);
     int am = m0 + row;
     am = am < p.M ? am : p.M - 1;
     voffa[t] = (unsigned)(((am - m0) * K + 8 * chunk) * 2);
@@ -574,6 +577,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, T == 4 ?
 #pragma unroll
   for (int jn = 0; jn < T; ++jn) {
     const int nb = n0 + 32 * T * wn + 32 * jn + 16 * kh;
+    if (nb >= p.Npad) continue;                 // the empty half of a ragged last column tile
     float bv[16];
     load_bias16<EPI>(p, nb, bv);
 #pragma unroll
@@ -606,9 +610,12 @@ int persistent_grid(int n_tiles) {
 // the large-tile kernel pays when the problem fills the chip with 256 x 256 tiles
 bool use_gemm256(const GemmArgs& a) {
   static int mode = getenv("BD_GEMM256") ? atoi(getenv("BD_GEMM256")) : 1;
-  if (!mode || a.Npad % 256 != 0 || a.n_real != a.Npad) return false;
+  if (!mode || a.n_real != a.Npad) return false;
+  // widths that are odd multiples of 128 (the reference's "large" size: 1152, 3456) run with a half-empty last
+  // column tile once that costs little (an eighth of the columns at most)
+  if (a.Npad % 256 != 0 && a.Npad < 1024) return false;
   if (a.K < 768) return false;        // few k-steps: the 128 x 128 kernel with two workgroups per CU hides its epilogue better
-  return (((long long)a.M + 255) / 256) * (a.Npad / 256) >= 128;
+  return (((long long)a.M + 255) / 256) * ((a.Npad + 255) / 256) >= 128;
 }
 // the deep-ring 128 x 128 kernel: a long K on few tiles (at most about one per CU)
 bool use_gemm128_ring(const GemmArgs& a) {
@@ -622,7 +629,7 @@ template <int EPI, bool DROP = false>
 int launch(const GemmArgs& a, hipStream_t s) {
   void* tok = bd_prof_on() ? bd_prof_begin(s) : nullptr;
   if (use_gemm256(a)) {
-    const long long nt = (((long long)a.M + 255) / 256) * (a.Npad / 256);
+    const long long nt = (((long long)a.M + 255) / 256) * ((a.Npad + 255) / 256);
     BD_SET_MAX_LDS((gemm256_kernel<EPI, DROP, 4, 4>), 4 * G256_STAGE);
     hipLaunchKernelGGL((gemm256_kernel<EPI, DROP, 4, 4>), dim3((unsigned)nt), dim3(256), 4 * G256_STAGE, s, a);
   } else if (use_gemm128_ring(a)) {

@@ -445,9 +445,10 @@ def test_attn_block_unsupported_shapes_are_refused(gpu_device):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,N,K", [(16411, 512, 768), (32768, 1536, 1024), (8200, 1024, 1024), (33000, 256, 832)])
+@pytest.mark.parametrize("M,N,K", [(16411, 512, 768), (32768, 1536, 1024), (8200, 1024, 1024), (33000, 256, 832),
+                                   (6700, 1152, 1152), (2600, 3456, 1152)])    # odd multiples of 128: half-empty last column tile
 def test_large_tile_gemm_all_epilogues(gpu_device, M, N, K):
-    """Shapes that take the 256 x 256-tile kernel (N % 256 == 0, >= 128 tiles): every epilogue against fp32 torch,
+    """Shapes that take the 256 x 256-tile kernel (>= 128 tiles; N a multiple of 256, or of 128 from 1024 on): every epilogue against fp32 torch,
     ragged last row tile included; exact for small-integer operands."""
     import ctypes as C
     from oracle import sampler_ref as ora

@@ -76,6 +76,8 @@ def test_small_config_logits_match_oracle(gpu_device):
     (256, 4, 2, 1024, 3, 128),     # the reference's "tiny" size: fused kernels with head_dim 64
     (1024, 16, 2, 4096, 2, 512),   # scaled-up stress shape (d = 1024, L = 512): unfused kernels
     (384, 3, 2, 1536, 3, 200),     # small backbone beyond 128 tokens: fused feed-forward, unfused attention
+    (768, 6, 2, 3072, 40, 128),    # the reference's "medium" size (config.yaml model_sizes), 5120 rows
+    (1152, 9, 2, 4608, 60, 128),   # its "large" size: widths that are odd multiples of 128, 7680 rows (large-tile GEMM)
 ])
 def test_other_architectures_match_oracle(gpu_device, hidden, heads, layers, ffn, B, L):
     cfg = dict(RI.SMALL_CFG, hidden_size=hidden, num_heads=heads, num_layers=layers, ffn_hidden_size=ffn,
