@@ -617,12 +617,12 @@ bool use_gemm256(const GemmArgs& a) {
   if (a.K < 768) return false;        // few k-steps: the 128 x 128 kernel with two workgroups per CU hides its epilogue better
   return (((long long)a.M + 255) / 256) * ((a.Npad + 255) / 256) >= 128;
 }
-// the deep-ring 128 x 128 kernel: a long K on few tiles (at most about one per CU)
+// the deep-ring 128 x 128 kernel: a long K on at most one tile per CU (3-7 % there, 20-40 % slower beyond)
 bool use_gemm128_ring(const GemmArgs& a) {
   static int mode = getenv("BD_GEMM128_RING") ? atoi(getenv("BD_GEMM128_RING")) : 1;
   if (!mode || a.n_real != a.Npad || a.K % 32 != 0) return false;
   if (mode == 2) return true;         // every shape (measurements)
-  return a.K >= 768 && a.n_tiles <= 320;
+  return a.K >= 1024 && a.n_tiles <= 256;       // one workgroup per CU: with more tiles than CUs the two-per-CU kernel wins
 }
 
 template <int EPI, bool DROP = false>
