@@ -100,3 +100,26 @@ def test_argument_errors_of_the_reference(gpu_device):
     ids, strings = smp.sample_with_lengths([0, 1, 2], show_progress=False)
     assert ids.shape == (3, 2) and (ids[:, 0] == tok.bos_token_id).all() and (ids[:, 1] == tok.eos_token_id).all()
     assert strings == ["", "", ""]
+
+
+@pytest.mark.parametrize("variant", ["smiles", "bpe", "group"])
+@pytest.mark.parametrize("d,heads,F", [(768, 6, 3072), (1152, 9, 4608)])
+def test_samplers_on_the_medium_and_large_widths(gpu_device, variant, d, heads, F):
+    """The reference's medium / large model widths (two layers): per-operation kernels for the denoiser, chosen-row
+    logits from hidden rows of that width (V = 39 in the step kernel, V = 233 / 803 through the row workspace), every
+    step replayed by the oracle."""
+    T, B, L = 6, 10, 48
+    _, tok = H.make_sampler(variant)
+    model = build_model(tok, gpu_device, T, heads=heads, layers=2, d=d, F=F)
+    smp, _ = H.make_sampler(variant, model=model, num_steps=T, device=str(gpu_device))
+    smp._core.seed = 23
+    smp._core.record = []
+    ids, strings = smp.sample(B, L, show_progress=False)
+    out = ids.cpu().numpy()
+    assert (out != tok.mask_token_id).all() and len(strings) == B
+    tb = H.oracle_tables(smp)
+    rec = smp._core.record
+    fixed = (rec[0]["ids_before"].numpy() != tb.mask_id).astype(np.uint8) if variant in ("smiles", "bpe") else None
+    o, _ = replay(rec, tb, T, L, 1.0, True, fixed)
+    of = ora.sample_fixup(tb, o["ids"], o["logits"], natural_eos=False, attn=o["attn"], has_eos=o["has_eos"])
+    np.testing.assert_array_equal(out, of["ids"])
