@@ -206,11 +206,17 @@ def test_guarded_muon_adamw_skips_nonfinite_steps(gpu_device):
     assert b.state_dict()["state"][3]["step"] == 3
 
 
-def test_training_steps_with_muon_reduce_the_loss(gpu_device):
-    """End to end: the diffusion training step with the Muon + AdamW optimizer learns a fixed batch."""
+@pytest.mark.parametrize("size", ["tiny", "medium_width", "large_width"])
+def test_training_steps_with_muon_reduce_the_loss(gpu_device, size):
+    """End to end: the diffusion training step with the Muon + AdamW optimizer learns a fixed batch; also at the
+    reference's medium and large widths (two layers: shape classes 768^2 / 3072 x 768 and 1152^2 / 4608 x 1152)."""
     from bidiff.model.diffusion import DiscreteMaskingDiffusion
     dev = gpu_device
     cfg = dict(RI.BACKBONE_CFGS["tiny_h2"])
+    if size == "medium_width":
+        cfg.update(hidden_size=768, num_heads=6, ffn_hidden_size=3072, num_layers=2)
+    elif size == "large_width":
+        cfg.update(hidden_size=1152, num_heads=9, ffn_hidden_size=4608, num_layers=2)
     torch.manual_seed(0)
     bb = DiffusionBackbone(**cfg)
     model = DiscreteMaskingDiffusion(bb, num_steps=cfg["num_diffusion_steps"], mask_token_id=1, pad_token_id=0,
