@@ -230,18 +230,25 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
   //      it must land before the next barrier) and 2 j + 8 (issued in the steps after those).
   // Step order: wait for this step's fragment, issue the read LOOK ahead, the step's GELU share, the MFMA: on one
   // wave per SIMD that order hides about four vector operations per step; read - wait - MFMA - vector exposes them.
-  // One piece inside the loop costs three instructions: the lane's offset into a unit (lane, wave and piece number)
-  // sits in a register per piece number, the unit's bases are scalars, M0 = LDS base + piece offset.
-  unsigned voff[PER_UNIT];
+  // A pair of pieces inside the loop costs four instructions: M0 = LDS base of the wave's part of the unit, a wait
+  // state, and two loads whose immediate offsets tell the pieces apart; the unit's bases are scalars.
+  // In the loop wave w moves the PER_UNIT consecutive fragments w PER_UNIT .. of a unit (global and LDS layouts of a
+  // unit are the same bytes): the instruction's immediate offset moves the global address and the LDS destination
+  // together, so four pieces share one lane-offset register.
+  constexpr int NVO = (PER_UNIT + 3) / 4;
+  unsigned voff[NVO];
 #pragma unroll
-  for (int k = 0; k < PER_UNIT; ++k) {
-    voff[k] = (unsigned)(lane * 16 + (wave + 4 * k) * 1024);
+  for (int k = 0; k < NVO; ++k) {
+    voff[k] = (unsigned)(lane * 16 + (wave * PER_UNIT + 4 * k) * 1024);
     asm volatile("" : "+v"(voff[k]));
   }
-  const unsigned ldsw = (unsigned)(size_t)(lds_void*)smem + wave * 1024;
-  auto dma_piece = [&](const unsigned char* unit_src, unsigned unit_lds, int k) {
-    asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"
-                 ::"s"(unit_lds), "i"(k * 4096), "v"(voff[k]), "s"(unit_src)
+  const unsigned ldsw = (unsigned)(size_t)(lds_void*)smem + wave * (PER_UNIT * 1024);
+  // pieces k and k + 1 (k even: both under one M0 value)
+  auto dma_pair = [&](const unsigned char* unit_src, unsigned unit_lds, int k) {
+    asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 offset:%4\n\t"
+                 "global_load_lds_dwordx4 %2, %3 offset:%5"
+                 ::"s"(unit_lds), "i"((k >> 2) * 4096), "v"(voff[k >> 2]), "s"(unit_src), "i"((k & 3) * 1024),
+                   "i"((k & 3) * 1024 + 1024)
                  : "memory", "m0", "scc");
   };
   bf16x8 wf[NF];
@@ -291,16 +298,17 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
       // DMA_GROUP pieces back to back (the stream into the CU runs at 17 B/clk with one piece in flight per wave, 23
       // with two, 24.7 at best: tools_prof/micro/stream_rate.hip); the two pieces of the next odd unit wait for the
       // barrier at step SYNC
+      static_assert(DMA_GROUP == 2 && PER_UNIT % 2 == 0 && (SYNC / DMA_EVERY) % 2 == 0, "pieces go out in pairs under one M0");
 #pragma unroll
-      for (int slot = 0; slot < 2 * PER_UNIT; ++slot) {
+      for (int slot = 0; slot < 2 * PER_UNIT; slot += 2) {
         const int at = slot >= SYNC / DMA_EVERY ? SYNC : (slot / DMA_GROUP) * (DMA_GROUP * DMA_EVERY);
         if (at != i) continue;
         if (slot >= SYNC / DMA_EVERY) {
-          if (odd_next) dma_piece(src_next, lds_next, slot - SYNC / DMA_EVERY);
+          if (odd_next) dma_pair(src_next, lds_next, slot - SYNC / DMA_EVERY);
         } else if (slot < PER_UNIT - 2) {
-          if (odd_rest) dma_piece(src_odd, lds_odd, slot + 2);
+          if (odd_rest) dma_pair(src_odd, lds_odd, slot + 2);
         } else {
-          if (even_all) dma_piece(src_even, lds_even, slot - (PER_UNIT - 2));
+          if (even_all) dma_pair(src_even, lds_even, slot - (PER_UNIT - 2));
         }
       }
       // wait for fragment i: younger reads in flight are the LOOK - 1 behind it, plus, in the tail, the four bias reads
@@ -396,18 +404,29 @@ __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* sm
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5;
-  // A unit moves as PER_UNIT 1-KiB pieces per wave, three instructions each: the lane's offset into a unit (lane, wave
-  // and piece number) sits in a register per piece number, the unit's global and LDS bases are scalars.
-  unsigned voff[PER_UNIT];
+  // A unit moves as PER_UNIT 1-KiB pieces per wave; the unit's global and LDS bases are scalars.
+  // In the loop wave w moves the PER_UNIT consecutive fragments w PER_UNIT .. of a unit (global and LDS layouts of a
+  // unit are the same bytes): the instruction's immediate offset moves the global address and the LDS destination
+  // together, so four pieces share one lane-offset register.
+  constexpr int NVO = (PER_UNIT + 3) / 4;
+  unsigned voff[NVO];
 #pragma unroll
-  for (int k = 0; k < PER_UNIT; ++k) {
-    voff[k] = (unsigned)(lane * 16 + (wave + 4 * k) * 1024);
+  for (int k = 0; k < NVO; ++k) {
+    voff[k] = (unsigned)(lane * 16 + (wave * PER_UNIT + 4 * k) * 1024);
     asm volatile("" : "+v"(voff[k]));
   }
-  const unsigned ldsw = (unsigned)(size_t)(lds_void*)smem + wave * 1024;
+  const unsigned ldsw = (unsigned)(size_t)(lds_void*)smem + wave * (PER_UNIT * 1024);
   auto dma_piece = [&](const unsigned char* unit_src, unsigned unit_lds, int k) {
-    asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"
-                 ::"s"(unit_lds), "i"(k * 4096), "v"(voff[k]), "s"(unit_src)
+    asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 offset:%4"
+                 ::"s"(unit_lds), "i"((k >> 2) * 4096), "v"(voff[k >> 2]), "s"(unit_src), "i"((k & 3) * 1024)
+                 : "memory", "m0", "scc");
+  };
+  // pieces k and k + 1 (k even: both under one M0 value)
+  auto dma_pair = [&](const unsigned char* unit_src, unsigned unit_lds, int k) {
+    asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 offset:%4\n\t"
+                 "global_load_lds_dwordx4 %2, %3 offset:%5"
+                 ::"s"(unit_lds), "i"((k >> 2) * 4096), "v"(voff[k >> 2]), "s"(unit_src), "i"((k & 3) * 1024),
+                   "i"((k & 3) * 1024 + 1024)
                  : "memory", "m0", "scc");
   };
   auto issue_unit = [&](int u) {
@@ -485,7 +504,7 @@ __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* sm
     for (int i = 0; i < NT; ++i) {
       if (i == MID) mid_sync();
       if (i >= MID && (i - MID) % 4 == 0 && (i - MID) / 2 < PER_UNIT) {      // in pairs: two in flight per wave
-        if (more) { dma_piece(next_src, next_lds, (i - MID) / 2); dma_piece(next_src, next_lds, (i - MID) / 2 + 1); }
+        if (more) dma_pair(next_src, next_lds, (i - MID) / 2);
       }
       const int j = i + LOOK;
       if (j < NT) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[j]) : "v"(bc), "i"(j * 1024));

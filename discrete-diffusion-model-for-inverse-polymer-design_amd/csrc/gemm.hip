@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
 // -------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(1))) void g256_glb;
 typedef __attribute__((address_space(3))) void g256_lds;
-constexpr int G256_STAGE = 32768, G256_PART = 16384;   // four stages of BK = 32
+constexpr int G256_STAGE = 32768;   // four stages of BK = 32 (256 weight rows and 256 activation rows x 64 B)
 // The same kernel on a 128 x 128 tile (T = 2: waves of 64 x 64) with an EIGHT-stage ring (16 KB per stage, seven
 // stages = 224 k-values in flight) serves the products with few tiles and a long K (the training step's N = 384,
 // K = 1152 / 1536 products: 240 tiles for 256 CUs). There the register-staged 128 x 128 kernel above has one k-step
