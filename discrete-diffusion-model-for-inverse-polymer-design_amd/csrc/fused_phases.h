@@ -263,20 +263,24 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
     for (int i = 0; i < LOOK; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[i]) : "v"(W1b), "i"(i * 1024));
   }
 
-#pragma nounroll
-  for (int j = 0; j < nch; ++j) {
-    unsigned W1b = lds0 + ((2 * j + 2) % RING) * UNIT;        // this iteration's GEMM1 unit
-    unsigned W2b = lds0 + ((2 * j + 1) % RING) * UNIT;        // this iteration's GEMM2 unit
-    unsigned W1n = lds0 + ((2 * j + 4) % RING) * UNIT;        // the next iteration's GEMM1 unit
+  // The ring has six slots and an iteration advances by two units: the slot numbers repeat every three iterations, so
+  // the body is instantiated for j % 3 = 0, 1, 2 and every slot offset is a constant (computed from j they cost about
+  // 35 scalar and vector instructions per iteration, a tenth of what a wave issues there).
+  static_assert(RING == 6, "the three-iteration period below assumes six slots, two units per iteration");
+  auto chunk_iteration = [&](const int j, auto phase) {
+    constexpr int PH = decltype(phase)::value;                 // j % 3
+    unsigned W1b = lds0 + ((2 * PH + 2) % RING) * UNIT;        // this iteration's GEMM1 unit
+    unsigned W2b = lds0 + ((2 * PH + 1) % RING) * UNIT;        // this iteration's GEMM2 unit
+    unsigned W1n = lds0 + ((2 * PH + 4) % RING) * UNIT;        // the next iteration's GEMM1 unit
     unsigned bbn = ldsb + 128 * (j + 2);                      // the next iteration's biases (zeros past the end)
     asm volatile("" : "+v"(W1b), "+v"(W2b), "+v"(W1n), "+v"(bbn));
     // global and LDS bases of the three units this iteration moves pieces of (scalar, once per iteration)
     const unsigned char* const src_odd = p.wpack + (size_t)(2 * j + 3) * UNIT;
     const unsigned char* const src_even = p.wpack + (size_t)(2 * j + 6) * UNIT;
     const unsigned char* const src_next = p.wpack + (size_t)(2 * j + 5) * UNIT;
-    const unsigned lds_odd = ldsw + ((2 * j + 3) % RING) * UNIT;
-    const unsigned lds_even = ldsw + ((2 * j + 6) % RING) * UNIT;
-    const unsigned lds_next = ldsw + ((2 * j + 5) % RING) * UNIT;
+    const unsigned lds_odd = ldsw + ((2 * PH + 3) % RING) * UNIT;
+    const unsigned lds_even = ldsw + ((2 * PH + 6) % RING) * UNIT;
+    const unsigned lds_next = ldsw + ((2 * PH + 5) % RING) * UNIT;
     const bool odd_rest = j >= 1 && 2 * j + 3 < nunits;       // pieces 2.. of unit 2 j + 3 (0 and 1 went out last iteration)
     const bool even_all = j >= 1 && 2 * j + 6 < nunits;       // unit 2 j + 6 (unit 6 went out before the loop)
     const bool odd_next = 2 * j + 5 < nunits;                 // pieces 0 and 1 of unit 2 j + 5
@@ -347,6 +351,17 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
     hn_cur = hn_next;
     hb[0] = hb0_next;
     asm volatile("" : "+v"(hb[0]), "+v"(hb[1]));
+  };
+  {
+    int j = 0;
+#pragma nounroll
+    for (; j + 3 <= nch; j += 3) {
+      chunk_iteration(j, std::integral_constant<int, 0>{});
+      chunk_iteration(j + 1, std::integral_constant<int, 1>{});
+      chunk_iteration(j + 2, std::integral_constant<int, 2>{});
+    }
+    if (j < nch) chunk_iteration(j, std::integral_constant<int, 0>{});
+    if (j + 1 < nch) chunk_iteration(j + 1, std::integral_constant<int, 1>{});
   }
   // the reads issued for the iteration after the last one
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
