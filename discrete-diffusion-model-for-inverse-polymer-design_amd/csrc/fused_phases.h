@@ -507,14 +507,20 @@ __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* sm
   };
   // One unit: NT fragments -> NT MFMAs, step(i, fragment) issues the MFMA of fragment i. The reads of the first LOOK
   // fragments of the following unit go out during the tail (after the last unit they fetch stale bytes nobody uses).
+  // LDS offsets of the ring slots of units u, u + 1, u + 2 and the global address of unit u + 2, carried from unit to
+  // unit (rotated at the end of stream_unit): computed from u they are three divisions by three, a dependent chain of
+  // multiply-high, shift and vector add in front of the first fragment read of every unit.
+  static_assert(RING == 3, "the slot rotation below assumes three slots");
+  unsigned ro0 = 0, ro1 = UNIT, ro2 = 2 * UNIT;
+  const unsigned char* src2 = p.wpack + 2 * (size_t)UNIT;
   auto stream_unit = [&](int u, auto&& step) {
-    unsigned bc = lds0 + (u % RING) * UNIT, bn = lds0 + ((u + 1) % RING) * UNIT;
+    unsigned bc = lds0 + ro0, bn = lds0 + ro1;
     asm volatile("" : "+v"(bc), "+v"(bn));
     // unit u + 2 goes out in pairs of pieces over the unit's second half: a burst of all pieces of all four waves at
     // the barrier queues up behind the CU's memory path, single pieces leave it half idle (17 B/clk against 23)
     const bool more = u + 2 < NUNITS;
-    const unsigned char* const next_src = p.wpack + (size_t)(u + 2) * UNIT;
-    const unsigned next_lds = ldsw + ((u + 2) % RING) * UNIT;
+    const unsigned char* const next_src = src2;
+    const unsigned next_lds = ldsw + ro2;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       if (i == MID) mid_sync();
@@ -528,6 +534,9 @@ __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* sm
       asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(wf[i]) : "i"(LOOK));
       step(i, wf[i]);
     }
+    const unsigned t = ro0;
+    ro0 = ro1; ro1 = ro2; ro2 = t;
+    src2 += UNIT;
   };
   // WEIGHT_IS_A: tile = W_frag * op (rows = weight rows), else tile = op * W_frag (rows = tokens).
   auto run_unit = [&](int u, auto weight_is_a, f32x16 t, const bf16x8 (&op)[NT]) -> f32x16 {
