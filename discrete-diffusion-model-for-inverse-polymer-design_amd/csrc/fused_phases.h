@@ -89,6 +89,14 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
   constexpr int DMA_EVERY = 4;                // one piece per four steps on average: 2 PER_UNIT pieces per iteration
   constexpr int DMA_GROUP = 2;                // issued in groups of this many (4 and 6 measure the same)
   static_assert(NT % 8 == 0 && NF / DMA_EVERY == 2 * PER_UNIT && PER_UNIT >= 2, "unsupported width");
+  // hand-over of the hidden tile inside the second GEMM (steps counted from NT): copy out of the accumulator in
+  // COPY_STEPS steps, then the next chunk's biases into it from step BIAS_AT on, PER registers per step; the biases are
+  // read at step BIAS_READ of the iteration and have landed LOOK steps later
+  constexpr int PER = NT >= 16 ? 2 : 4;
+  constexpr int COPY_STEPS = 2 + 8 / PER;
+  constexpr int BIAS_READ = NT >= 16 ? NT : NT - 4;
+  constexpr int BIAS_AT = BIAS_READ + LOOK - NT > COPY_STEPS ? BIAS_READ + LOOK - NT : COPY_STEPS;
+  static_assert(BIAS_READ >= 0 && BIAS_AT + 16 / PER <= NT, "copy, then biases, inside the second GEMM");
   float* const sb1 = (float*)(smem + RING * UNIT);     // F + 64 floats
   typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
   typedef const __attribute__((address_space(3))) f32x4* lds_f4;
@@ -210,6 +218,13 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
     hn_cur = hn_next;
     hb[0] = hb0_next;
     hb[1] = hb0_next;                // defined value; overwritten before its first real use
+    // the hidden tile of iteration 0 starts from chunk 1's biases (inside the loop an iteration sets up the next one's)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b = *(lds_f4)(size_t)(ldsb + 128 + 32 * q);
+      hn_next[4 * q + 0] = b[0]; hn_next[4 * q + 1] = b[1]; hn_next[4 * q + 2] = b[2]; hn_next[4 * q + 3] = b[3];
+    }
+    asm volatile("" : "+a"(hn_next));          // in its accumulation registers here, not at the head of the loop
     // every wave is done with unit 0: unit 6 takes its slot (the loop issues odd units from 5, even units from 8)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -253,12 +268,10 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
   };
   bf16x8 wf[NF];
   f32x4 bq[4];
-  // start the stream for iteration 0: biases of chunk 1, fragments 0 .. LOOK - 1 of unit 2
+  // start the stream for iteration 0: fragments 0 .. LOOK - 1 of unit 2
   {
-    unsigned W1b = lds0 + 2 * UNIT, bb1 = ldsb + 128;
-    asm volatile("" : "+v"(W1b), "+v"(bb1));
-#pragma unroll
-    for (int q = 0; q < 4; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[q]) : "v"(bb1), "i"(32 * q));
+    unsigned W1b = lds0 + 2 * UNIT;
+    asm volatile("" : "+v"(W1b));
 #pragma unroll
     for (int i = 0; i < LOOK; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[i]) : "v"(W1b), "i"(i * 1024));
   }
@@ -284,12 +297,10 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
     const bool odd_rest = j >= 1 && 2 * j + 3 < nunits;       // pieces 2.. of unit 2 j + 3 (0 and 1 went out last iteration)
     const bool even_all = j >= 1 && 2 * j + 6 < nunits;       // unit 2 j + 6 (unit 6 went out before the loop)
     const bool odd_next = 2 * j + 5 < nunits;                 // pieces 0 and 1 of unit 2 j + 5
-    // biases are the oldest reads in flight; the LOOK fragments behind them may stay
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]) : "i"(LOOK));
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      hn_next[4 * q + 0] = bq[q][0]; hn_next[4 * q + 1] = bq[q][1]; hn_next[4 * q + 2] = bq[q][2]; hn_next[4 * q + 3] = bq[q][3];
-    }
+    // Nothing stands between the last MFMA of an iteration and the first of the next: the finished hidden tile is
+    // copied out of its accumulator (hn_next -> hn_cur) during the first steps of the second GEMM, and the accumulator
+    // takes the next chunk's biases during later ones (as a block at the head of the iteration the 16 reads, 16 writes
+    // and the wait state behind them left the matrix core idle for about 130 cycles per iteration).
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
@@ -316,11 +327,15 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
         }
       }
       // wait for fragment i: younger reads in flight are the LOOK - 1 behind it, plus, in the tail, the four bias reads
-      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(wf[i]) : "i"(i > SYNC ? LOOK + 3 : LOOK - 1));
-      if (i == SYNC) {
+      // (the four bias reads go out at step BIAS_READ, in front of that step's fragment read: they are younger than
+      // the fragments of steps BIAS_READ + 1 .. BIAS_READ + LOOK - 1 and older than the one of step BIAS_READ + LOOK,
+      // whose wait covers them)
+      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(wf[i]) : "i"(i > BIAS_READ && i < BIAS_READ + LOOK ? LOOK + 3 : LOOK - 1));
+      if (i == BIAS_READ) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[q]) : "v"(bbn), "i"(32 * q));
       }
+      if (i == BIAS_READ + LOOK) asm volatile("" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]));     // landed
       {
         // fragment i + LOOK of the stream: GEMM1 unit, GEMM2 unit, then the next iteration's GEMM1 unit
         const unsigned base = i >= SYNC ? W1n : (i + LOOK < NT ? W1b : W2b);
@@ -334,9 +349,26 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
 #pragma unroll
         for (int g = GH + i * GH / NT; g < GH + (i + 1) * GH / NT; ++g) gelu_part(g, hn_cur, hb[1]);
       } else {
-        // first half of GELU(hn_next) -> hb0_next, beside GEMM2
+        const int k = i - NT;
+        // the finished tile leaves its accumulator: registers 0 .. 7 (first half of the GELU, needed from here on) in
+        // the first two steps, 8 .. 15 in the steps behind them, PER registers per step
+        if (k < 2) {
 #pragma unroll
-        for (int g = (i - NT) * GH / NT; g < (i - NT + 1) * GH / NT; ++g) gelu_part(g, hn_next, hb0_next);
+          for (int e = 0; e < 4; ++e) hn_cur[4 * k + e] = hn_next[4 * k + e];
+        } else if (k < COPY_STEPS) {
+#pragma unroll
+          for (int e = 0; e < PER; ++e) hn_cur[8 + PER * (k - 2) + e] = hn_next[8 + PER * (k - 2) + e];
+        }
+        if (k < COPY_STEPS) asm volatile("" : "+v"(hn_cur));       // the copy happens in this step
+        // then the accumulator takes the next chunk's biases, PER registers per step
+        if (k >= BIAS_AT && k < BIAS_AT + 16 / PER) {
+#pragma unroll
+          for (int e = PER * (k - BIAS_AT); e < PER * (k - BIAS_AT + 1); ++e) hn_next[e] = bq[e / 4][e % 4];
+          asm volatile("" : "+a"(hn_next));                        // written into the accumulator in this step
+        }
+        // first half of GELU(the copied tile) -> hb0_next, beside GEMM2
+#pragma unroll
+        for (int g = k * GH / NT; g < (k + 1) * GH / NT; ++g) gelu_part(g, hn_cur, hb0_next);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (i < NT) {
@@ -348,7 +380,6 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
       }
       __builtin_amdgcn_sched_barrier(0);     // nothing moves between fragment steps
     }
-    hn_cur = hn_next;
     hb[0] = hb0_next;
     asm volatile("" : "+v"(hb[0]), "+v"(hb[1]));
   };
