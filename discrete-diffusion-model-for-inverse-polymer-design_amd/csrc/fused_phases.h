@@ -19,9 +19,9 @@ struct Gelu4 { unsigned x[2], s[2], p[2]; };
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // bytes of LDS the phases need
-__host__ __device__ constexpr size_t ffn_phase_lds(int NT, int F) { return 6 * (size_t)NT * 1024 + ((size_t)F + 64) * 4; }
+__host__ __device__ constexpr size_t ffn_phase_lds(int NT, int F) { return 6 * (size_t)NT * 1024 + ((size_t)F + 64) * 4 + (size_t)NT * 16 * 4; }
 __host__ __device__ constexpr size_t attn_phase_lds(int NT, int DH, int H) {
-  return 3 * (size_t)NT * 1024 + 2 * (size_t)128 * DH * 2 + (size_t)H * DH * 4 + 128 * 4;
+  return 3 * (size_t)NT * 1024 + 2 * (size_t)128 * DH * 2 + (size_t)H * DH * 4 + 128 * 4 + 2 * (size_t)NT * 16 * 4;
 }
 
 // Loads / stores of the wave's 32 rows in accumulator layout: acc[T][4 q + e] = row[32 T + 8 q + 4 h + e]
@@ -62,7 +62,7 @@ __device__ __forceinline__ void stagger_start(int stagger_blocks, int stagger_un
 
 // ---------------------------------------------------------------------------------------------
 // Feed-forward phase: acc (in) = the wave's 32 residual rows, acc (out) = rows + W2 GELU(W1 LN(rows)
-// + b1) + b2. smem: 6 units + (F + 64) floats. All four waves of the workgroup call it together;
+// + b1) + b2. smem: 6 units + (F + 64) + d floats. All four waves of the workgroup call it together;
 // nobody may still be using smem when they enter.
 struct FfnPhase {
   const unsigned char* wpack;   // packed weight stream (bd_ffn_pack_weights)
@@ -98,6 +98,8 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
   constexpr int BIAS_AT = BIAS_READ + LOOK - NT > COPY_STEPS ? BIAS_READ + LOOK - NT : COPY_STEPS;
   static_assert(BIAS_READ >= 0 && BIAS_AT + 16 / PER <= NT, "copy, then biases, inside the second GEMM");
   float* const sb1 = (float*)(smem + RING * UNIT);     // F + 64 floats
+  float* const sb2 = sb1 + p.F + 64;                   // D floats: the output bias, staged with the other table (read
+                                                       // from memory at the end of the phase its latency stands alone)
   typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
   typedef const __attribute__((address_space(3))) f32x4* lds_f4;
 
@@ -121,6 +123,7 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
 #pragma unroll
   for (int u = 0; u < 5; ++u) issue_unit(u);            // F >= 96: the first five units exist
   for (int i = tid; i < p.F + 64; i += 256) sb1[i] = i < p.F ? p.b1[i] : 0.f;
+  for (int i = tid; i < D; i += 256) sb2[i] = p.b2[i];
 
   // ---- LayerNorm -> bf16 B operands (gamma / beta are folded into W1 and b1)
   bf16x8 xln[NT];
@@ -402,7 +405,7 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
   for (int T = 0; T < NT32; ++T)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f32x4 b = *(const f32x4*)(p.b2 + 32 * T + 8 * q + 4 * h);
+      const f32x4 b = *(lds_f4)(size_t)((unsigned)(size_t)(lds_void*)sb2 + (32 * T + 8 * q + 4 * h) * 4);
       acc[T][4 * q + 0] += b[0]; acc[T][4 * q + 1] += b[1]; acc[T][4 * q + 2] += b[2]; acc[T][4 * q + 3] += b[3];
     }
 }
@@ -412,7 +415,7 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
 // sequence), acc (out) = rows + Wo MHA(LN(rows)) + bias. The rows never leave the accumulation
 // registers: every head adds its slice of the output projection to them as soon as its attention
 // output exists.
-// smem: 3 units + K and V fragments (2 x 256 dh bytes... 128 keys) + H dh + 128 floats.
+// smem: 3 units + K and V fragments (2 x 256 dh bytes... 128 keys) + H dh + 128 + 2 d floats.
 // H heads of DH features each; H DH may exceed d (heads zero-padded to a width the MFMA tiles divide: the padded
 // q / k features add nothing to the scores, the padded v features meet zero columns of Wo).
 struct AttnPhase {
@@ -446,6 +449,7 @@ __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* sm
   unsigned char* const sV = sK + KV_BYTES;
   float* const sbias = (float*)(sV + KV_BYTES);        // H dh floats (q bias)
   float* const smask = sbias + AW;                 // 128 floats: 0 (visible) or -1e30
+  float* const sbo = smask + 128;                  // 2 D floats: output bias without / with the folded v bias
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -489,6 +493,7 @@ __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* sm
     issue_unit(0);
     issue_unit(1);
     for (int i = tid; i < AW; i += 256) sbias[i] = p.bq[i];
+    for (int i = tid; i < 2 * D; i += 256) sbo[i] = i < D ? p.bo[i] : p.bo_fold[i - D];
     if (tid < 128) {
       const bool vis = tid < p.L && (p.keymask == nullptr || p.keymask[tid] != 0);
       smask[tid] = vis ? 0.f : -1e30f;
@@ -735,7 +740,7 @@ __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* sm
   for (int T = 0; T < NT32; ++T)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f32x4 b = *(const f32x4*)((dead ? p.bo : p.bo_fold) + 32 * T + 8 * q + 4 * h);
+      const f32x4 b = *(lds_f4)(size_t)((unsigned)(size_t)(lds_void*)sbo + ((dead ? 0 : D) + 32 * T + 8 * q + 4 * h) * 4);
       acc[T][4 * q + 0] += b[0]; acc[T][4 * q + 1] += b[1]; acc[T][4 * q + 2] += b[2]; acc[T][4 * q + 3] += b[3];
     }
 }
