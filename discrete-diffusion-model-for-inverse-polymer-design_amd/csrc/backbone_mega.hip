@@ -41,6 +41,7 @@ struct MegaArgs {
   int B, L, F, n_layers;
   float eps;
   int stagger_blocks, stagger_units;
+  int tables_by_dma;             // every bias table 16-byte aligned: fetched by LDS-DMA one phase ahead
   MegaLayer layers[MEGA_MAX_LAYERS];
 };
 
@@ -86,6 +87,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   fp.F = p.F;
   fp.eps = p.eps;
 
+  // Both phases' tables (biases, key mask values) live behind everything the phases put into LDS and are fetched by
+  // LDS-DMA one phase ahead: filled at the head of the phase that uses them, their loads from memory (and the wait for
+  // the first weight pieces in front of them, loads return in order) stood between the phases twelve times per
+  // sequence. The key mask values are the sequence's own and are written once.
+  constexpr int AW = H * DH;
+  float* const tabF = (float*)(smem + phase_tables_base(NT, DH));       // first biases (F + 64, zeros past F), second biases (d)
+  float* const tabA = tabF + p.F + 64 + D;                                // q biases (H dh), key mask values (128), output biases (2 d)
+  int turn = 0;
+  auto fetch_attn_tables = [&](const MegaLayer& lw) {
+    fetch_table(lw.bq, tabA, AW * 4, wave, lane, turn);
+    fetch_table(lw.bo, tabA + AW + 128, D * 4, wave, lane, turn);
+    fetch_table(lw.bo_fold, tabA + AW + 128 + D, D * 4, wave, lane, turn);
+  };
+  auto fetch_ffn_tables = [&](const MegaLayer& lw) {
+    fetch_table(lw.b1, tabF, p.F * 4, wave, lane, turn);
+    fetch_table(lw.b2, tabF + p.F + 64, D * 4, wave, lane, turn);
+  };
+  if (p.tables_by_dma) {
+    fetch_attn_tables(p.layers[0]);
+    if (threadIdx.x < 64) tabF[p.F + threadIdx.x] = 0.f;
+    if (threadIdx.x < 128) {
+      const bool vis = (int)threadIdx.x < L && (ap.keymask == nullptr || ap.keymask[threadIdx.x] != 0);
+      tabA[AW + threadIdx.x] = vis ? 0.f : -1e30f;
+    }
+    ap.tables = tabA;
+    fp.tables = tabF;
+  }
+
 #pragma nounroll
   for (int l = 0; l < p.n_layers; ++l) {
     const MegaLayer& lw = p.layers[l];
@@ -95,10 +124,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (p.tables_by_dma) fetch_ffn_tables(lw);                 // nobody reads the feed-forward tables before the next barrier
     attn_phase<NT, DH, H>(ap, smem, acc);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (p.tables_by_dma && l + 1 < p.n_layers) fetch_attn_tables(p.layers[l + 1]);    // the attention phase is done with its own
     ffn_phase<NT>(fp, smem, acc);
   }
 
@@ -138,9 +169,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 template <int NT, int DH, int H = NT * 16 / DH>
 int launch_mega(const MegaArgs& a, hipStream_t stream) {
   const size_t la = attn_phase_lds(NT, DH, H), lf = ffn_phase_lds(NT, a.F);
-  const size_t lds = la > lf ? la : lf;
+  const size_t lt = phase_tables_base(NT, DH) + ffn_tables_bytes(NT, a.F) + attn_tables_bytes(NT, DH, H);
+  MegaArgs b = a;
+  if (lt > 160 * 1024) b.tables_by_dma = 0;              // no room for both phases' tables side by side: filled per phase
+  const size_t lds = b.tables_by_dma ? lt : (la > lf ? la : lf);
   BD_SET_MAX_LDS((backbone_mega_kernel<NT, DH, H>), lds);
-  hipLaunchKernelGGL((backbone_mega_kernel<NT, DH, H>), dim3(a.B), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((backbone_mega_kernel<NT, DH, H>), dim3(b.B), dim3(256), lds, stream, b);
   return bd_check_launch("bd_backbone_mega");
 }
 
@@ -177,6 +211,15 @@ extern "C" int bd_backbone_mega(const bd_backbone_desc* desc, const long long* i
     const bd_layer_weights& lw = c.layers[i];
     a.layers[i] = MegaLayer{(const unsigned char*)lw.attn_pack, lw.b_q_attn, lw.b_o, lw.b_o_fold,
                             (const unsigned char*)lw.ffn_pack, lw.b_fc1_ln, lw.b_fc2};
+  }
+  {
+    static const int off = getenv("BD_MEGA_TABLES_DMA") ? atoi(getenv("BD_MEGA_TABLES_DMA")) == 0 : 0;
+    size_t bits = 0;
+    for (int i = 0; i < c.n_layers; ++i) {
+      const bd_layer_weights& lw = c.layers[i];
+      bits |= (size_t)lw.b_q_attn | (size_t)lw.b_o | (size_t)lw.b_o_fold | (size_t)lw.b_fc1_ln | (size_t)lw.b_fc2;
+    }
+    a.tables_by_dma = !off && (bits & 15) == 0 && c.ffn % 4 == 0;
   }
   {
     static int ncu = 0;

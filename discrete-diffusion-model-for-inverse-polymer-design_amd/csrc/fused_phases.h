@@ -24,6 +24,30 @@ __host__ __device__ constexpr size_t attn_phase_lds(int NT, int DH, int H) {
   return 3 * (size_t)NT * 1024 + 2 * (size_t)128 * DH * 2 + (size_t)H * DH * 4 + 128 * 4 + 2 * (size_t)NT * 16 * 4;
 }
 
+// Where the single-launch forward keeps both phases' tables: behind everything either phase puts into LDS, so that
+// a phase's tables can be fetched while the other phase runs.
+__host__ __device__ constexpr size_t phase_tables_base(int NT, int DH) {
+  const size_t a = 3 * (size_t)NT * 1024 + 2 * (size_t)128 * DH * 2, f = 6 * (size_t)NT * 1024;
+  return a > f ? a : f;
+}
+__host__ __device__ constexpr size_t ffn_tables_bytes(int NT, int F) { return ((size_t)F + 64 + (size_t)NT * 16) * 4; }
+__host__ __device__ constexpr size_t attn_tables_bytes(int NT, int DH, int H) { return ((size_t)H * DH + 128 + 2 * (size_t)NT * 16) * 4; }
+
+// `bytes` (a multiple of 16) from global memory to LDS by LDS-DMA, 1-KiB pieces dealt to the four waves in turn
+// (`turn` counts the pieces across calls). The caller waits for its own pieces (vmcnt) and meets the other waves at a
+// barrier before anybody reads the table.
+__device__ __forceinline__ void fetch_table(const float* src, float* dst, int bytes, int wave, int lane, int& turn) {
+  const unsigned lds = (unsigned)(size_t)(lds_void*)dst;
+  for (int off = 0; off < bytes; off += 1024) {
+    if ((turn++ & 3) == wave && off + lane * 16 < bytes) {
+      const unsigned m0v = __builtin_amdgcn_readfirstlane(lds + off);
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                   ::"s"(m0v), "v"((unsigned)(off + lane * 16)), "s"(src)
+                   : "memory", "m0");
+    }
+  }
+}
+
 // Loads / stores of the wave's 32 rows in accumulator layout: acc[T][4 q + e] = row[32 T + 8 q + 4 h + e]
 template <int NT32>
 __device__ __forceinline__ void load_rows(f32x16 (&acc)[NT32], const float* xrow) {
@@ -70,6 +94,10 @@ struct FfnPhase {
   const float* b2;              // [d]
   int F;
   float eps;
+  // the phase's tables ((F + 64) floats of first biases, zeros past F, then d floats of second biases) at a caller's
+  // place in LDS, already filled (the single-launch forward fetches them during the phase before); null: behind the
+  // ring, filled here
+  float* tables = nullptr;
 };
 
 template <int NT>
@@ -97,7 +125,7 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
   constexpr int BIAS_READ = NT >= 16 ? NT : NT - 4;
   constexpr int BIAS_AT = BIAS_READ + LOOK - NT > COPY_STEPS ? BIAS_READ + LOOK - NT : COPY_STEPS;
   static_assert(BIAS_READ >= 0 && BIAS_AT + 16 / PER <= NT, "copy, then biases, inside the second GEMM");
-  float* const sb1 = (float*)(smem + RING * UNIT);     // F + 64 floats
+  float* const sb1 = p.tables ? p.tables : (float*)(smem + RING * UNIT);     // F + 64 floats
   float* const sb2 = sb1 + p.F + 64;                   // D floats: the output bias, staged with the other table (read
                                                        // from memory at the end of the phase its latency stands alone)
   typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
@@ -122,8 +150,10 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
 
 #pragma unroll
   for (int u = 0; u < 5; ++u) issue_unit(u);            // F >= 96: the first five units exist
-  for (int i = tid; i < p.F + 64; i += 256) sb1[i] = i < p.F ? p.b1[i] : 0.f;
-  for (int i = tid; i < D; i += 256) sb2[i] = p.b2[i];
+  if (p.tables == nullptr) {
+    for (int i = tid; i < p.F + 64; i += 256) sb1[i] = i < p.F ? p.b1[i] : 0.f;
+    for (int i = tid; i < D; i += 256) sb2[i] = p.b2[i];
+  }
 
   // ---- LayerNorm -> bf16 B operands (gamma / beta are folded into W1 and b1)
   bf16x8 xln[NT];
@@ -426,6 +456,9 @@ struct AttnPhase {
   const unsigned char* keymask; // this SEQUENCE's byte mask [L] (non-zero = visible) or null
   int L;
   float eps;
+  // the phase's tables (H dh floats of q biases, 128 floats of key mask values, 2 d floats of output biases) at a
+  // caller's place in LDS, already filled; null: behind the K / V fragments, filled here
+  float* tables = nullptr;
 };
 
 template <int NT, int DH, int H>
@@ -447,7 +480,7 @@ __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* sm
   static_assert(NT % 4 == 0 && DH % 32 == 0 && NT % KBO == 0 && AW >= D, "unsupported shape");
   unsigned char* const sK = smem + RING * UNIT;
   unsigned char* const sV = sK + KV_BYTES;
-  float* const sbias = (float*)(sV + KV_BYTES);        // H dh floats (q bias)
+  float* const sbias = p.tables ? p.tables : (float*)(sV + KV_BYTES);        // H dh floats (q bias)
   float* const smask = sbias + AW;                 // 128 floats: 0 (visible) or -1e30
   float* const sbo = smask + 128;                  // 2 D floats: output bias without / with the folded v bias
 
@@ -492,11 +525,13 @@ __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* sm
   {
     issue_unit(0);
     issue_unit(1);
-    for (int i = tid; i < AW; i += 256) sbias[i] = p.bq[i];
-    for (int i = tid; i < 2 * D; i += 256) sbo[i] = i < D ? p.bo[i] : p.bo_fold[i - D];
-    if (tid < 128) {
-      const bool vis = tid < p.L && (p.keymask == nullptr || p.keymask[tid] != 0);
-      smask[tid] = vis ? 0.f : -1e30f;
+    if (p.tables == nullptr) {
+      for (int i = tid; i < AW; i += 256) sbias[i] = p.bq[i];
+      for (int i = tid; i < 2 * D; i += 256) sbo[i] = i < D ? p.bo[i] : p.bo_fold[i - D];
+      if (tid < 128) {
+        const bool vis = tid < p.L && (p.keymask == nullptr || p.keymask[tid] != 0);
+        smask[tid] = vis ? 0.f : -1e30f;
+      }
     }
     float s = 0.f;
 #pragma unroll
