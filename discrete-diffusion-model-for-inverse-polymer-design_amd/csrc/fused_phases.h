@@ -38,11 +38,13 @@ __host__ __device__ constexpr size_t attn_tables_bytes(int NT, int DH, int H) { 
 // barrier before anybody reads the table.
 __device__ __forceinline__ void fetch_table(const float* src, float* dst, int bytes, int wave, int lane, int& turn) {
   const unsigned lds = (unsigned)(size_t)(lds_void*)dst;
+  unsigned lane16 = lane * 16;
+  asm volatile("" : "+v"(lane16));        // recomputed at every call: hoisted out of the layer loop the offsets get spilled
   for (int off = 0; off < bytes; off += 1024) {
-    if ((turn++ & 3) == wave && off + lane * 16 < bytes) {
+    if ((turn++ & 3) == wave && off + lane16 < (unsigned)bytes) {
       const unsigned m0v = __builtin_amdgcn_readfirstlane(lds + off);
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                   ::"s"(m0v), "v"((unsigned)(off + lane * 16)), "s"(src)
+                   ::"s"(m0v), "v"(off + lane16), "s"(src)
                    : "memory", "m0");
     }
   }
@@ -771,13 +773,17 @@ __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* sm
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
   // ---- + bias
+  // (three tiles' worth of bias reads in flight at a time: left alone, the compiler issues all of them first and
+  // spills the registers they need)
 #pragma unroll
-  for (int T = 0; T < NT32; ++T)
+  for (int T = 0; T < NT32; ++T) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x4 b = *(lds_f4)(size_t)((unsigned)(size_t)(lds_void*)sbo + ((dead ? 0 : D) + 32 * T + 8 * q + 4 * h) * 4);
       acc[T][4 * q + 0] += b[0]; acc[T][4 * q + 1] += b[1]; acc[T][4 * q + 2] += b[2]; acc[T][4 * q + 3] += b[3];
     }
+    if (T % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+  }
 }
 
 }  // namespace bdf
