@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int D = NT * 16;
   constexpr int NT32 = NT / 2;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = lane >> 5, c = lane & 31;
   const int seq = blockIdx.x, L = p.L;
   const int tok = 32 * wave + c;

@@ -133,7 +133,9 @@ __device__ __forceinline__ void ffn_phase(const FfnPhase& p, unsigned char* smem
   typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
   typedef const __attribute__((address_space(3))) f32x4* lds_f4;
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));     // per-lane offsets are recomputed in every phase: hoisted out of the caller's layer loop they spill
+  const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: LDS-DMA targets stay scalar
   const int h = lane >> 5;
   const int nch = p.F >> 5;
@@ -486,7 +488,9 @@ __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* sm
   float* const smask = sbias + AW;                 // 128 floats: 0 (visible) or -1e30
   float* const sbo = smask + 128;                  // 2 D floats: output bias without / with the folded v bias
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));     // as in the feed-forward phase
+  const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5;
   // A unit moves as PER_UNIT 1-KiB pieces per wave; the unit's global and LDS bases are scalars.
