@@ -42,6 +42,7 @@ struct MegaArgs {
   float eps;
   int stagger_blocks, stagger_units;
   int tables_by_dma;             // every bias table 16-byte aligned: fetched by LDS-DMA one phase ahead
+  int seg_waves;                 // waves per sequence: 4, or 2 / 1 when L <= 64 / 32 (two / four sequences share a workgroup)
   MegaLayer layers[MEGA_MAX_LAYERS];
 };
 
@@ -52,9 +53,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = lane >> 5, c = lane & 31;
-  const int seq = blockIdx.x, L = p.L;
-  const int tok = 32 * wave + c;
-  const bool valid = tok < L;
+  // Sequences of at most 64 (32) tokens share a workgroup in twos (fours): the weight stream, which is what a
+  // workgroup costs, then serves two (four) of them, and no wave computes rows that only shadow a last row. The
+  // sequences' keys sit side by side in the 128-key tiles; each wave's mask table hides the others' keys.
+  const int L = p.L, SW = p.seg_waves, NSEG = 4 >> (SW >> 1);      // SW = 4, 2, 1
+  const int seg = wave >> (SW >> 1);
+  const int seq_own = (int)blockIdx.x * NSEG + seg;
+  const bool seq_ok = seq_own < p.B;                    // the last workgroup may have fewer sequences than segments
+  const int seq = seq_ok ? seq_own : p.B - 1;
+  const int tok = 32 * (wave & (SW - 1)) + c;
+  const bool valid = seq_ok && tok < L;
   const int tokc = valid ? tok : L - 1;                 // lanes past the sequence shadow its last row
   const size_t row = (size_t)seq * L + tokc;
   stagger_start(p.stagger_blocks, p.stagger_units);
@@ -80,7 +88,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 
   AttnPhase ap;
-  ap.keymask = p.keymask ? p.keymask + (size_t)seq * L : nullptr;
+  ap.keymask = p.keymask ? p.keymask + (size_t)seq * L : nullptr;      // (read by the phase only when it fills its own tables)
   ap.L = L;
   ap.eps = p.eps;
   FfnPhase fp;
@@ -107,9 +115,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if (p.tables_by_dma) {
     fetch_attn_tables(p.layers[0]);
     if (threadIdx.x < 64) tabF[p.F + threadIdx.x] = 0.f;
-    if (threadIdx.x < 128) {
-      const bool vis = (int)threadIdx.x < L && (ap.keymask == nullptr || ap.keymask[threadIdx.x] != 0);
-      tabA[AW + threadIdx.x] = vis ? 0.f : -1e30f;
+    if (NSEG == 1) {
+      if (threadIdx.x < 128) {
+        const bool vis = (int)threadIdx.x < L && (ap.keymask == nullptr || ap.keymask[threadIdx.x] != 0);
+        tabA[AW + threadIdx.x] = vis ? 0.f : -1e30f;
+      }
+    } else {
+      // one table per segment behind the attention tables: key j of the tiles is token j - 32 SW s of segment s
+      float* const tabM = tabA + AW + 128 + 2 * D;
+      if (threadIdx.x < 128)
+        for (int s = 0; s < NSEG; ++s) {
+          const int sq = (int)blockIdx.x * NSEG + s, j = (int)threadIdx.x - 32 * SW * s;
+          const bool vis = sq < p.B && j >= 0 && j < 32 * SW && j < L &&
+                           (p.keymask == nullptr || p.keymask[(size_t)sq * L + j] != 0);
+          tabM[128 * s + threadIdx.x] = vis ? 0.f : -1e30f;
+        }
+      ap.wave_mask = tabM + 128 * seg;
     }
     ap.tables = tabA;
     fp.tables = tabF;
@@ -172,9 +193,14 @@ int launch_mega(const MegaArgs& a, hipStream_t stream) {
   const size_t lt = phase_tables_base(NT, DH) + ffn_tables_bytes(NT, a.F) + attn_tables_bytes(NT, DH, H);
   MegaArgs b = a;
   if (lt > 160 * 1024) b.tables_by_dma = 0;              // no room for both phases' tables side by side: filled per phase
-  const size_t lds = b.tables_by_dma ? lt : (la > lf ? la : lf);
+  // short sequences share a workgroup only with the prefetched tables (the per-segment mask tables sit behind them)
+  const size_t lm = lt + 4 * 128 * sizeof(float);
+  if (!b.tables_by_dma || lm > 160 * 1024) b.seg_waves = 4;
+  const size_t lds = b.tables_by_dma ? (b.seg_waves < 4 ? lm : lt) : (la > lf ? la : lf);
+  const int nseg = 4 / b.seg_waves, blocks = (b.B + nseg - 1) / nseg;
+  if (blocks < 4 * b.stagger_blocks) b.stagger_blocks = 0;
   BD_SET_MAX_LDS((backbone_mega_kernel<NT, DH, H>), lds);
-  hipLaunchKernelGGL((backbone_mega_kernel<NT, DH, H>), dim3(b.B), dim3(256), lds, stream, b);
+  hipLaunchKernelGGL((backbone_mega_kernel<NT, DH, H>), dim3(blocks), dim3(256), lds, stream, b);
   return bd_check_launch("bd_backbone_mega");
 }
 
@@ -220,6 +246,8 @@ extern "C" int bd_backbone_mega(const bd_backbone_desc* desc, const long long* i
       bits |= (size_t)lw.b_q_attn | (size_t)lw.b_o | (size_t)lw.b_o_fold | (size_t)lw.b_fc1_ln | (size_t)lw.b_fc2;
     }
     a.tables_by_dma = !off && (bits & 15) == 0 && c.ffn % 4 == 0;
+    const char* e = getenv("BD_MEGA_PACK");            // 0: one sequence per workgroup whatever L (for comparisons)
+    a.seg_waves = (e && atoi(e) == 0) ? 4 : L <= 32 ? 1 : L <= 64 ? 2 : 4;
   }
   {
     static int ncu = 0;

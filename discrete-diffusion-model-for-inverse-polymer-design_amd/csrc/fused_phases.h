@@ -463,6 +463,9 @@ struct AttnPhase {
   // the phase's tables (H dh floats of q biases, 128 floats of key mask values, 2 d floats of output biases) at a
   // caller's place in LDS, already filled; null: behind the K / V fragments, filled here
   float* tables = nullptr;
+  // this WAVE's 128 key mask values in LDS when the workgroup's waves do not all see the same keys (several short
+  // sequences sharing the workgroup: a wave's table hides the other sequences' keys); null: the phase's own table
+  const float* wave_mask = nullptr;
 };
 
 template <int NT, int DH, int H>
@@ -566,7 +569,7 @@ __device__ __forceinline__ void attn_phase(const AttnPhase& p, unsigned char* sm
   const unsigned ldsK = (unsigned)(size_t)(lds_void*)sK + lane * 16;
   const unsigned ldsV = (unsigned)(size_t)(lds_void*)sV + lane * 16;
   const unsigned ldsB = (unsigned)(size_t)(lds_void*)sbias;
-  const unsigned ldsM = (unsigned)(size_t)(lds_void*)smask + 16 * h;
+  const unsigned ldsM = (unsigned)(size_t)(lds_void*)(p.wave_mask ? p.wave_mask : smask) + 16 * h;
 
   // The weight stream is consumed as ONE continuous sequence of fragments. One unit = NT fragments
   // -> NT MFMAs on one 32x32 accumulator; fragment i of a unit lives in register wf[i], and its LDS

@@ -145,6 +145,43 @@ def test_single_launch_forward_equals_per_layer_kernels(gpu_device):
     assert _lib.lib().bd_backbone_mega_supported(C.byref(bbg.packed().desc), 129) == 0
 
 
+@pytest.mark.parametrize("hidden,heads,ffn", [(384, 3, 1536), (384, 8, 1536), (256, 4, 1024), (128, 4, 512)])
+def test_short_sequences_sharing_a_workgroup_change_nothing(gpu_device, hidden, heads, ffn, monkeypatch):
+    """Up to 64 (32) tokens, two (four) sequences share a workgroup of the single-launch forward, side by side in the
+    key tiles and hidden from each other by per-wave mask tables. Every attended row must come out with the bits of
+    the one-sequence-per-workgroup launch (BD_MEGA_PACK=0), for batch sizes that leave the last workgroup
+    partly empty, ragged key masks included; one case is also held against the oracle."""
+    from bidiff import _lib
+    import ctypes as C
+    cfg = dict(RI.SMALL_CFG, hidden_size=hidden, num_heads=heads, num_layers=2, ffn_hidden_size=ffn, dropout=0.0)
+    torch.manual_seed(3)
+    bb = DiffusionBackbone(**cfg).eval()
+    RI.perturb_state_dict(bb.state_dict(), 21)
+    sd = {k: v.clone() for k, v in bb.state_dict().items()}
+    bbg = bb.to(gpu_device)
+    for L in (17, 24, 32, 33, 64, 65):
+        for B in (1, 5, 8):
+            ids, attn, t = (torch.from_numpy(x) for x in RI.backbone_inputs(cfg, 100 + L + B, B=B, L=L))
+            assert _lib.lib().bd_backbone_mega_supported(C.byref(bbg.packed().desc), L) == 1
+            dev = [x.to(gpu_device) for x in (ids, t, attn)]
+            with torch.no_grad():
+                monkeypatch.setenv("BD_MEGA_PACK", "0")
+                alone = bbg.get_hidden_states(*dev).cpu()
+                monkeypatch.delenv("BD_MEGA_PACK")
+                shared = bbg.get_hidden_states(*dev).cpu()
+                nomask = bbg.get_hidden_states(dev[0], dev[1], None).cpu()
+                monkeypatch.setenv("BD_MEGA_PACK", "0")
+                nomask_alone = bbg.get_hidden_states(dev[0], dev[1], None).cpu()
+                monkeypatch.delenv("BD_MEGA_PACK")
+            valid = attn.bool()
+            assert torch.isfinite(shared[valid]).all()
+            assert torch.equal(shared[valid], alone[valid]), (L, B)
+            assert torch.equal(nomask, nomask_alone), (L, B)
+            if (L, B) == (33, 5):
+                ref = BR.hidden_states(sd, cfg, ids, t, attn, layer_idx=-1).numpy()
+                assert rel_err(shared.numpy()[valid.numpy()], ref[valid.numpy()]) < BF16_TOL
+
+
 def test_cpu_tensors_fail_loudly():
     cfg, bb = tiny_model("tiny_h2")
     ids, attn, t = RI.backbone_inputs(cfg, 21)
