@@ -456,6 +456,8 @@ def main():
         for name, fn in (("selfies", lambda: variant_bench(dev, "selfies", B, L, T, world, rank)),
                          ("group_selfies", lambda: variant_bench(dev, "group", B, L, T, world, rank)),
                          ("smiles_bpe", lambda: variant_bench(dev, "bpe", B, L, 50, world, rank)),
+                         # sequences of at most 64 tokens: two per workgroup of the single-launch forward
+                         ("selfies_L64", lambda: variant_bench(dev, "selfies", B, 64, T, world, rank)),
                          ("c5_24L_d1024_L512", lambda: c5_bench(dev, args.c5_batch, 512, T))):
             torch.cuda.empty_cache()
             try:
