@@ -179,6 +179,10 @@ SIGNATURES = {
                                       C.c_longlong, VP, VP, VP]),
     "bd_backbone_mega_supported": (C.c_int, [C.POINTER(BackboneDesc), C.c_int]),
     "bd_backbone_mega": (C.c_int, [C.POINTER(BackboneDesc), VP, VP, VP, C.c_int, C.c_int, VP, VP, VP]),
+    "bd_backbone_mega_ragged_supported": (C.c_int, [C.POINTER(BackboneDesc), C.c_int]),
+    "bd_backbone_mega_ragged": (C.c_int, [C.POINTER(BackboneDesc), VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP, VP]),
+    "bd_backbone_forward_ragged": (C.c_int, [C.POINTER(BackboneDesc), VP, VP, VP, VP, C.c_int, C.c_int, C.c_int,
+                                             VP, C.c_longlong, VP, VP, VP]),
     "bd_backbone_forward_layers": (C.c_int, [C.POINTER(BackboneDesc), VP, VP, VP, C.c_int, C.c_int, VP,
                                              C.c_longlong, C.c_int, VP, VP]),
     "bd_corrupt": (C.c_int, [VP, VP, VP, VP, C.c_int, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -399,10 +399,46 @@ class DiffusionBackbone(nn.Module):
             logits = logits.view(B, L, V)
         return (h.view(B, L, d) if want_hidden else None), logits
 
+    def ragged_wave_table(self, lengths, L, device=None):
+        """Deal sequences of the given attended lengths (host integers, one per sequence of a [B, L] batch) to the
+        32-row waves of the single-launch forward's workgroups: a sequence takes ceil(length / 32) adjacent waves,
+        first-fit by decreasing size. Returns the int32 [n_blocks, 4] table for ``run_forward(wave_table=...)``, or
+        None when this model / L has no such launch or the table would not save a tenth of the workgroups."""
+        if self.compute_dtype != "bf16" or L > 128:
+            return None
+        pk = self.packed()
+        if _lib.lib().bd_backbone_mega_ragged_supported(C.byref(pk.desc), int(L)) != 1:
+            return None
+        need = [max(1, min(4, -(-min(int(n), L) // 32))) for n in lengths]
+        B = len(need)
+        per_block = 4 if L <= 32 else 2 if L <= 64 else 1            # what the launch does by itself
+        table, free = [], {1: [], 2: [], 3: []}
+        for i in sorted(range(B), key=lambda k: -need[k]):
+            w = need[i]
+            blk = None
+            for f in range(w, 4):
+                if free[f]:
+                    blk, have = free[f].pop(), f
+                    break
+            if blk is None:
+                table.append([-1, -1, -1, -1])
+                blk, have = len(table) - 1, 4
+            row = table[blk]
+            row[4 - have:4 - have + w] = [i] * w
+            if have - w > 0:
+                free[have - w].append(blk)
+        if len(table) * 10 > -(-B // per_block) * 9:
+            return None
+        dev = device if device is not None else self.token_embedding.weight.device
+        return torch.tensor(table, dtype=torch.int32).to(dev)
+
     def run_forward(self, input_ids, timesteps, keymask, want_hidden=True, want_logits=False,
-                    hidden_out=None, logits_out=None):
+                    hidden_out=None, logits_out=None, wave_table=None):
         """One inference forward on the current stream. keymask: uint8 [B,L] or None.
-        Returns (hidden bf16 [B,L,d] or None, logits fp32 [B,L,V] or None)."""
+        Returns (hidden bf16 [B,L,d] or None, logits fp32 [B,L,V] or None).
+        wave_table (int32 [n_blocks, 4] on the device, from ``ragged_wave_table``): the single-launch forward with
+        sequences of different lengths dealt to the waves of its workgroups; rows beyond a sequence's waves are
+        not computed (hidden rows there keep what ``hidden_out`` held)."""
         timesteps = self._check_inputs(input_ids, timesteps)
         ids = input_ids.to(torch.long).contiguous()
         B, L = ids.shape
@@ -424,6 +460,16 @@ class DiffusionBackbone(nn.Module):
             hidden_out = torch.empty(B, L, self.hidden_size, dtype=torch.bfloat16, device=ids.device)
         if want_logits and logits_out is None:
             logits_out = torch.empty(B, L, self.vocab_size, dtype=torch.float32, device=ids.device)
+        if wave_table is not None:
+            if wave_table.dtype != torch.int32 or wave_table.dim() != 2 or wave_table.shape[1] != 4 \
+                    or not wave_table.is_contiguous() or wave_table.device != ids.device:
+                raise ValueError("wave_table must be a contiguous int32 [n_blocks, 4] tensor on the inputs' device")
+            rc = _lib.lib().bd_backbone_forward_ragged(
+                C.byref(pk.desc), _lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(keymask), _lib.ptr(wave_table),
+                int(wave_table.shape[0]), B, L, _lib.ptr(ws), need, _lib.ptr(hidden_out) if want_hidden else None,
+                _lib.ptr(logits_out) if want_logits else None, _lib.stream_handle())
+            _lib.check(rc, "bd_backbone_forward_ragged")
+            return (hidden_out if want_hidden else None), (logits_out if want_logits else None)
         rc = _lib.lib().bd_backbone_forward(
             C.byref(pk.desc), _lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(keymask), B, L,
             _lib.ptr(ws), need, _lib.ptr(hidden_out) if want_hidden else None,

@@ -125,6 +125,9 @@ class ReverseSampler:
         # as one product ahead of the draws): None = when the vocabulary is large enough to pay (V > 128).
         self.row_workspace: Optional[bool] = None
         self.row_cap_max = 16
+        # Sequences shorter than the batch's padded length share workgroups of the single-launch forward (False: every
+        # sequence computes all L rows, padding included).
+        self.ragged = True
 
     def _tables(self):
         if self._dt is None:
@@ -163,7 +166,15 @@ class ReverseSampler:
             seed = int(torch.randint(0, 2**62, (1,)).item())
         ktab = self._ktable(L)
         d = backbone.hidden_size
-        hidden = torch.empty(B, L, d, dtype=torch.bfloat16, device=dev)
+        # Batches padded to their longest row: deal the sequences to the forward's waves by their own lengths (one
+        # device -> host copy per call). Lengths only shrink during a run (natural EOS), so the table stays valid;
+        # rows beyond a sequence's waves are never drawn, read or repaired, and stay zero.
+        wave_table = None
+        if self.ragged and 32 < L <= 128 and hasattr(backbone, "ragged_wave_table"):
+            lens = ((attn != 0) * torch.arange(1, L + 1, device=dev)).amax(1)
+            if int(lens.min().item()) <= (L - 1) // 32 * 32:         # somebody needs fewer waves than the padded length
+                wave_table = backbone.ragged_wave_table(lens.tolist(), L, dev)
+        hidden = (torch.zeros if wave_table is not None else torch.empty)(B, L, d, dtype=torch.bfloat16, device=dev)
         logits = None
         pk = backbone.packed()
         lib = _lib.lib()
@@ -217,13 +228,15 @@ class ReverseSampler:
             if full:
                 if logits is None:
                     logits = torch.empty(B, L, tt.V, dtype=torch.float32, device=dev)
-                backbone.run_forward(ids, ts, keymask, want_hidden=False, want_logits=True, logits_out=logits)
+                backbone.run_forward(ids, ts, keymask, want_hidden=False, want_logits=True, logits_out=logits,
+                                     **({} if wave_table is None else {"wave_table": wave_table}))
                 raw = logits.clone() if self.record is not None else None
                 a.hidden, a.wout, a.logits = None, None, logits.data_ptr()
                 a.row_logits, a.row_pos, a.row_cap = None, None, 0
                 final_logits = logits
             else:
-                backbone.run_forward(ids, ts, keymask, want_hidden=True, want_logits=False, hidden_out=hidden)
+                backbone.run_forward(ids, ts, keymask, want_hidden=True, want_logits=False, hidden_out=hidden,
+                                     **({} if wave_table is None else {"wave_table": wave_table}))
                 a.hidden, a.wout = hidden.data_ptr(), pk.w_out.data_ptr()
                 if use_rows:
                     a.row_logits, a.row_pos, a.row_cap = row_logits.data_ptr(), row_pos.data_ptr(), row_cap

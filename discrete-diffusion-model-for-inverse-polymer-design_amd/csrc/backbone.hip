@@ -150,6 +150,38 @@ extern "C" int bd_backbone_forward(const bd_backbone_desc* desc, const long long
                       hidden_out, logits_out, stream);
 }
 
+extern "C" int bd_backbone_forward_ragged(const bd_backbone_desc* desc, const long long* ids,
+                                          const long long* timesteps, const unsigned char* keymask,
+                                          const int* wave_seq, int n_blocks, int B, int L, void* workspace,
+                                          long long workspace_bytes, void* hidden_out, float* logits_out,
+                                          void* stream) {
+  if (desc == nullptr) return bd_fail(BD_ERR_ARG, "backbone: null descriptor");
+  int rc = check_desc(desc);
+  if (rc != BD_OK) return rc;
+  const bd_backbone_desc& c = *desc;
+  BD_REQUIRE(ids && timesteps && workspace && wave_seq, "bd_backbone_forward_ragged: null operand");
+  BD_REQUIRE(B > 0 && L > 0 && n_blocks > 0, "bd_backbone_forward_ragged: empty batch");
+  BD_REQUIRE(L <= c.max_pos, "bd_backbone_forward_ragged: sequence length %d exceeds max_position_embeddings %d", L,
+             c.max_pos);
+  BD_REQUIRE(hidden_out != nullptr || logits_out != nullptr, "bd_backbone_forward_ragged: no output");
+  const long long M = (long long)B * L;
+  BD_REQUIRE(M < (1ll << 31), "bd_backbone_forward_ragged: too many tokens");
+  const Carve w = carve(c, M);
+  BD_REQUIRE(workspace_bytes >= w.total, "bd_backbone_forward_ragged: workspace %lld < %lld bytes", workspace_bytes,
+             w.total);
+  BD_REQUIRE(logits_out == nullptr || c.w_out != nullptr, "bd_backbone_forward_ragged: logits need w_out");
+  void* hf = hidden_out ? hidden_out : (char*)workspace + w.h;
+  if (hidden_out == nullptr) {
+    // rows no wave computes must still be finite operands of the vocabulary head
+    if (hipMemsetAsync(hf, 0, (size_t)M * c.d * 2, (hipStream_t)stream) != hipSuccess)
+      return bd_fail(BD_ERR_LAUNCH, "bd_backbone_forward_ragged: clearing the hidden rows failed");
+  }
+  if ((rc = bd_backbone_mega_ragged(desc, ids, timesteps, keymask, wave_seq, n_blocks, B, L, hf, stream))) return rc;
+  if (logits_out != nullptr)
+    return bd_gemm_bf16(hf, c.w_out, nullptr, logits_out, (int)M, c.vocab_pad, c.vocab, c.d, c.vocab, 3, stream);
+  return BD_OK;
+}
+
 extern "C" int bd_backbone_forward_layers(const bd_backbone_desc* desc, const long long* ids,
                                           const long long* timesteps, const unsigned char* keymask, int B,
                                           int L, void* workspace, long long workspace_bytes, int n_run,

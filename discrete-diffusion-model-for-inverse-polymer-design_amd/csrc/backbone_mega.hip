@@ -43,6 +43,7 @@ struct MegaArgs {
   int stagger_blocks, stagger_units;
   int tables_by_dma;             // every bias table 16-byte aligned: fetched by LDS-DMA one phase ahead
   int seg_waves;                 // waves per sequence: 4, or 2 / 1 when L <= 64 / 32 (two / four sequences share a workgroup)
+  const int* wave_seq;           // [gridDim.x, 4] sequence of each wave (-1: none), equal entries adjacent; null: the rule above
   MegaLayer layers[MEGA_MAX_LAYERS];
 };
 
@@ -53,16 +54,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = lane >> 5, c = lane & 31;
-  // Sequences of at most 64 (32) tokens share a workgroup in twos (fours): the weight stream, which is what a
-  // workgroup costs, then serves two (four) of them, and no wave computes rows that only shadow a last row. The
-  // sequences' keys sit side by side in the 128-key tiles; each wave's mask table hides the others' keys.
+  // Short sequences share a workgroup: the weight stream, which is what a workgroup costs, then serves several of them,
+  // and no wave computes rows that only shadow a last row. By rule: sequences of at most 64 (32) tokens in twos
+  // (fours). By the caller's table: wave w works on rows 32 (w - first wave of its run) .. of sequence wave_seq[w], so
+  // sequences of different lengths fill the four waves (rows beyond a sequence's waves are not computed at all).
+  // The sequences' keys sit side by side in the 128-key tiles; each wave's mask table hides the others' keys.
   const int L = p.L, SW = p.seg_waves, NSEG = 4 >> (SW >> 1);      // SW = 4, 2, 1
-  const int seg = wave >> (SW >> 1);
-  const int seq_own = (int)blockIdx.x * NSEG + seg;
-  const bool seq_ok = seq_own < p.B;                    // the last workgroup may have fewer sequences than segments
-  const int seq = seq_ok ? seq_own : p.B - 1;
-  const int tok = 32 * (wave & (SW - 1)) + c;
-  const bool valid = seq_ok && tok < L;
+  const bool shared = p.wave_seq != nullptr || NSEG > 1;
+  int sq[4], fw[4];                                      // per wave: sequence (-1: none), first wave of its run
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    sq[w] = p.wave_seq ? p.wave_seq[4 * (size_t)blockIdx.x + w] : (int)blockIdx.x * NSEG + (w >> (SW >> 1));
+    if (sq[w] < 0 || sq[w] >= p.B) sq[w] = -1;           // the last workgroup may have fewer sequences than segments
+  }
+  fw[0] = 0;
+#pragma unroll
+  for (int w = 1; w < 4; ++w) fw[w] = (sq[w] >= 0 && sq[w] == sq[w - 1]) ? fw[w - 1] : w;
+  auto of_wave = [](const int (&a)[4], int w) { return w == 0 ? a[0] : w == 1 ? a[1] : w == 2 ? a[2] : a[3]; };
+  const int seq_own = of_wave(sq, wave), first = of_wave(fw, wave);
+  const int seq = seq_own >= 0 ? seq_own : 0;
+  const int tok = 32 * (wave - first) + c;
+  const bool valid = seq_own >= 0 && tok < L;
   const int tokc = valid ? tok : L - 1;                 // lanes past the sequence shadow its last row
   const size_t row = (size_t)seq * L + tokc;
   stagger_start(p.stagger_blocks, p.stagger_units);
@@ -115,22 +127,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if (p.tables_by_dma) {
     fetch_attn_tables(p.layers[0]);
     if (threadIdx.x < 64) tabF[p.F + threadIdx.x] = 0.f;
-    if (NSEG == 1) {
+    if (!shared) {
       if (threadIdx.x < 128) {
         const bool vis = (int)threadIdx.x < L && (ap.keymask == nullptr || ap.keymask[threadIdx.x] != 0);
         tabA[AW + threadIdx.x] = vis ? 0.f : -1e30f;
       }
     } else {
-      // one table per segment behind the attention tables: key j of the tiles is token j - 32 SW s of segment s
+      // one table per wave behind the attention tables: key j of the tiles belongs to wave j / 32's sequence, and a wave
+      // sees it if both are in the same run of waves
       float* const tabM = tabA + AW + 128 + 2 * D;
-      if (threadIdx.x < 128)
-        for (int s = 0; s < NSEG; ++s) {
-          const int sq = (int)blockIdx.x * NSEG + s, j = (int)threadIdx.x - 32 * SW * s;
-          const bool vis = sq < p.B && j >= 0 && j < 32 * SW && j < L &&
-                           (p.keymask == nullptr || p.keymask[(size_t)sq * L + j] != 0);
-          tabM[128 * s + threadIdx.x] = vis ? 0.f : -1e30f;
-        }
-      ap.wave_mask = tabM + 128 * seg;
+      if (threadIdx.x < 128) {
+        const int kw = threadIdx.x >> 5;
+        const int ksq = of_wave(sq, kw), kfw = of_wave(fw, kw);
+        const int kpos = 32 * (kw - kfw) + ((int)threadIdx.x & 31);
+        const bool kvis = ksq >= 0 && kpos < L && (p.keymask == nullptr || p.keymask[(size_t)ksq * L + kpos] != 0);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) tabM[128 * w + threadIdx.x] = (kvis && kfw == fw[w]) ? 0.f : -1e30f;
+      }
+      ap.wave_mask = tabM + 128 * wave;
     }
     ap.tables = tabA;
     fp.tables = tabF;
@@ -188,16 +202,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 template <int NT, int DH, int H = NT * 16 / DH>
-int launch_mega(const MegaArgs& a, hipStream_t stream) {
+int launch_mega(const MegaArgs& a, int n_blocks, hipStream_t stream) {
   const size_t la = attn_phase_lds(NT, DH, H), lf = ffn_phase_lds(NT, a.F);
   const size_t lt = phase_tables_base(NT, DH) + ffn_tables_bytes(NT, a.F) + attn_tables_bytes(NT, DH, H);
   MegaArgs b = a;
   if (lt > 160 * 1024) b.tables_by_dma = 0;              // no room for both phases' tables side by side: filled per phase
   // short sequences share a workgroup only with the prefetched tables (the per-segment mask tables sit behind them)
   const size_t lm = lt + 4 * 128 * sizeof(float);
-  if (!b.tables_by_dma || lm > 160 * 1024) b.seg_waves = 4;
-  const size_t lds = b.tables_by_dma ? (b.seg_waves < 4 ? lm : lt) : (la > lf ? la : lf);
-  const int nseg = 4 / b.seg_waves, blocks = (b.B + nseg - 1) / nseg;
+  if (!b.tables_by_dma || lm > 160 * 1024) {
+    b.seg_waves = 4;
+    BD_REQUIRE(b.wave_seq == nullptr, "bd_backbone_mega_ragged: this model leaves no room for the per-wave mask tables");
+  }
+  const bool shared = b.seg_waves < 4 || b.wave_seq != nullptr;
+  const size_t lds = b.tables_by_dma ? (shared ? lm : lt) : (la > lf ? la : lf);
+  const int nseg = 4 / b.seg_waves, blocks = b.wave_seq ? n_blocks : (b.B + nseg - 1) / nseg;
   if (blocks < 4 * b.stagger_blocks) b.stagger_blocks = 0;
   BD_SET_MAX_LDS((backbone_mega_kernel<NT, DH, H>), lds);
   hipLaunchKernelGGL((backbone_mega_kernel<NT, DH, H>), dim3(blocks), dim3(256), lds, stream, b);
@@ -219,9 +237,21 @@ extern "C" int bd_backbone_mega_supported(const bd_backbone_desc* c, int L) {
   return 1;
 }
 
-extern "C" int bd_backbone_mega(const bd_backbone_desc* desc, const long long* ids, const long long* timesteps,
-                                const unsigned char* keymask, int B, int L, float* xbuf, void* hidden_out,
-                                void* stream_) {
+namespace {
+bool mega_tables_by_dma(const bd_backbone_desc& c) {
+  const char* e = getenv("BD_MEGA_TABLES_DMA");
+  if (e && atoi(e) == 0) return false;
+  size_t bits = 0;
+  for (int i = 0; i < c.n_layers; ++i) {
+    const bd_layer_weights& lw = c.layers[i];
+    bits |= (size_t)lw.b_q_attn | (size_t)lw.b_o | (size_t)lw.b_o_fold | (size_t)lw.b_fc1_ln | (size_t)lw.b_fc2;
+  }
+  return (bits & 15) == 0 && c.ffn % 4 == 0;
+}
+
+int mega_impl(const bd_backbone_desc* desc, const long long* ids, const long long* timesteps,
+              const unsigned char* keymask, const int* wave_seq, int n_blocks, int B, int L, float* xbuf,
+              void* hidden_out, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   BD_REQUIRE(desc && ids && timesteps && hidden_out, "bd_backbone_mega: null operand");
   BD_REQUIRE(B > 0, "bd_backbone_mega: B=%d", B);
@@ -233,19 +263,14 @@ extern "C" int bd_backbone_mega(const bd_backbone_desc* desc, const long long* i
   a.lnf_g = c.lnf_g; a.lnf_b = c.lnf_b;
   a.xbuf = xbuf; a.hidden = (unsigned short*)hidden_out;
   a.B = B; a.L = L; a.F = c.ffn; a.n_layers = c.n_layers; a.eps = c.ln_eps;
+  a.wave_seq = wave_seq;
   for (int i = 0; i < c.n_layers; ++i) {
     const bd_layer_weights& lw = c.layers[i];
     a.layers[i] = MegaLayer{(const unsigned char*)lw.attn_pack, lw.b_q_attn, lw.b_o, lw.b_o_fold,
                             (const unsigned char*)lw.ffn_pack, lw.b_fc1_ln, lw.b_fc2};
   }
   {
-    static const int off = getenv("BD_MEGA_TABLES_DMA") ? atoi(getenv("BD_MEGA_TABLES_DMA")) == 0 : 0;
-    size_t bits = 0;
-    for (int i = 0; i < c.n_layers; ++i) {
-      const bd_layer_weights& lw = c.layers[i];
-      bits |= (size_t)lw.b_q_attn | (size_t)lw.b_o | (size_t)lw.b_o_fold | (size_t)lw.b_fc1_ln | (size_t)lw.b_fc2;
-    }
-    a.tables_by_dma = !off && (bits & 15) == 0 && c.ffn % 4 == 0;
+    a.tables_by_dma = mega_tables_by_dma(c);
     const char* e = getenv("BD_MEGA_PACK");            // 0: one sequence per workgroup whatever L (for comparisons)
     a.seg_waves = (e && atoi(e) == 0) ? 4 : L <= 32 ? 1 : L <= 64 ? 2 : 4;
   }
@@ -269,15 +294,37 @@ extern "C" int bd_backbone_mega(const bd_backbone_desc* desc, const long long* i
   const int d = c.d, dh = bd_attn_block_width(d, c.n_heads) / c.n_heads;
   void* tok = bd_prof_on() ? bd_prof_begin(stream) : nullptr;
   int rc;
-  if (d == 384 && c.n_heads == 8) rc = launch_mega<24, 64, 8>(a, stream);
-  else if (d == 384 && dh == 128) rc = launch_mega<24, 128>(a, stream);
-  else if (d == 384) rc = launch_mega<24, 64>(a, stream);
-  else if (d == 256 && dh == 128) rc = launch_mega<16, 128>(a, stream);
-  else if (d == 256) rc = launch_mega<16, 64>(a, stream);
-  else if (dh == 64) rc = launch_mega<8, 64>(a, stream);
-  else rc = launch_mega<8, 32>(a, stream);
+  if (d == 384 && c.n_heads == 8) rc = launch_mega<24, 64, 8>(a, n_blocks, stream);
+  else if (d == 384 && dh == 128) rc = launch_mega<24, 128>(a, n_blocks, stream);
+  else if (d == 384) rc = launch_mega<24, 64>(a, n_blocks, stream);
+  else if (d == 256 && dh == 128) rc = launch_mega<16, 128>(a, n_blocks, stream);
+  else if (d == 256) rc = launch_mega<16, 64>(a, n_blocks, stream);
+  else if (dh == 64) rc = launch_mega<8, 64>(a, n_blocks, stream);
+  else rc = launch_mega<8, 32>(a, n_blocks, stream);
   // algorithmic work of the layers: projections, attention products, feed-forward
   if (tok) bd_prof_end(tok, stream, (double)c.n_layers * 2.0 * (double)B * L * (4.0 * d * d + 2.0 * L * d + 2.0 * d * c.ffn),
                        BD_PROF_MEGA);
   return rc;
+}
+}  // namespace
+
+extern "C" int bd_backbone_mega(const bd_backbone_desc* desc, const long long* ids, const long long* timesteps,
+                                const unsigned char* keymask, int B, int L, float* xbuf, void* hidden_out,
+                                void* stream) {
+  return mega_impl(desc, ids, timesteps, keymask, nullptr, 0, B, L, xbuf, hidden_out, stream);
+}
+
+extern "C" int bd_backbone_mega_ragged_supported(const bd_backbone_desc* c, int L) {
+  if (!bd_backbone_mega_supported(c, L) || !mega_tables_by_dma(*c)) return 0;
+  const int nt = c->d / 16, aw = bd_attn_block_width(c->d, c->n_heads), dh = aw / c->n_heads;
+  const size_t lt = phase_tables_base(nt, dh) + ffn_tables_bytes(nt, c->ffn) + attn_tables_bytes(nt, dh, c->n_heads);
+  return lt + 4 * 128 * sizeof(float) <= 160 * 1024;
+}
+
+extern "C" int bd_backbone_mega_ragged(const bd_backbone_desc* desc, const long long* ids, const long long* timesteps,
+                                       const unsigned char* keymask, const int* wave_seq, int n_blocks, int B, int L,
+                                       void* hidden_out, void* stream) {
+  BD_REQUIRE(wave_seq != nullptr && n_blocks > 0, "bd_backbone_mega_ragged: no wave table");
+  BD_REQUIRE(desc && bd_backbone_mega_ragged_supported(desc, L), "bd_backbone_mega_ragged: unsupported model shape or L=%d", L);
+  return mega_impl(desc, ids, timesteps, keymask, wave_seq, n_blocks, B, L, nullptr, hidden_out, stream);
 }

@@ -205,6 +205,24 @@ int bd_backbone_mega_supported(const bd_backbone_desc* desc, int L);
 int bd_backbone_mega(const bd_backbone_desc* desc, const long long* ids, const long long* timesteps,
                      const unsigned char* keymask, int B, int L, float* xbuf, void* hidden_out, void* stream);
 
+/* The single-launch forward for batches whose sequences are shorter than the padded length L (the
+ * reverse loop on per-sample lengths, src/sampling/sampler.py:747-812, pads a batch to its longest row): the
+ * caller deals the sequences to the four 32-row waves of each workgroup, wave_seq [n_blocks, 4] int32 on
+ * the device holding the sequence of each wave (-1: none), the waves of one sequence adjacent and in row
+ * order. A sequence with w waves gets its rows 0 .. 32 w - 1 computed (w = ceil(attended length / 32));
+ * hidden_out rows beyond them are NOT written, rows inside them equal bd_backbone_mega's bit for bit.
+ * Every sequence must appear in exactly one run of waves. bd_backbone_forward_ragged adds the
+ * vocabulary head over all B * L rows like bd_backbone_forward (hidden_out or logits_out may be null;
+ * the workspace is the one of bd_backbone_forward). */
+int bd_backbone_mega_ragged_supported(const bd_backbone_desc* desc, int L);
+int bd_backbone_mega_ragged(const bd_backbone_desc* desc, const long long* ids, const long long* timesteps,
+                            const unsigned char* keymask, const int* wave_seq, int n_blocks, int B, int L,
+                            void* hidden_out, void* stream);
+int bd_backbone_forward_ragged(const bd_backbone_desc* desc, const long long* ids, const long long* timesteps,
+                               const unsigned char* keymask, const int* wave_seq, int n_blocks, int B, int L,
+                               void* workspace, long long workspace_bytes, void* hidden_out, float* logits_out,
+                               void* stream);
+
 /* Embeddings + the first n_run blocks only; resid_out [B*L, d] fp32 receives the residual stream
  * (no final LayerNorm). Replaces get_hidden_states(layer_idx = n_run - 1 >= 0),
  * src/model/backbone.py:259-299. */

@@ -182,6 +182,54 @@ def test_short_sequences_sharing_a_workgroup_change_nothing(gpu_device, hidden, 
                 assert rel_err(shared.numpy()[valid.numpy()], ref[valid.numpy()]) < BF16_TOL
 
 
+@pytest.mark.parametrize("hidden,heads,ffn", [(384, 3, 1536), (384, 8, 1536), (128, 4, 512)])
+def test_ragged_batches_deal_sequences_to_waves(gpu_device, hidden, heads, ffn):
+    """A batch padded to its longest row, sequences dealt to the 32-row waves of the single-launch forward by their
+    own lengths (bd_backbone_forward_ragged): every sequence sits in exactly one run of adjacent waves, and every
+    row inside its waves carries the bits of the ordinary launch; rows beyond them keep what the buffer held."""
+    cfg = dict(RI.SMALL_CFG, hidden_size=hidden, num_heads=heads, num_layers=2, ffn_hidden_size=ffn, dropout=0.0)
+    torch.manual_seed(4)
+    bb = DiffusionBackbone(**cfg).eval()
+    RI.perturb_state_dict(bb.state_dict(), 22)
+    bbg = bb.to(gpu_device)
+    rs = np.random.RandomState(5)
+    for L, B in ((100, 37), (128, 64), (64, 21), (40, 9)):
+        lens = rs.randint(0, L + 1, size=B)
+        lens[0], lens[1] = L, 1
+        attn = (np.arange(L)[None] < lens[:, None]).astype(np.int64)
+        attn[2, : lens[2] // 2] = 0                      # a mask that is not a prefix: its last visible row counts
+        ids = rs.randint(5, cfg["vocab_size"], size=(B, L)).astype(np.int64) * attn
+        t = rs.randint(1, cfg["num_diffusion_steps"] + 1, size=B).astype(np.int64)
+        ids_d, t_d, attn_d = (torch.from_numpy(x).to(gpu_device) for x in (ids, t, attn))
+        km = (attn_d != 0).to(torch.uint8)
+        table = bbg.ragged_wave_table(lens.tolist(), L, gpu_device)
+        assert table is not None and table.dtype == torch.int32 and table.shape[1] == 4
+        tb = table.cpu().numpy()
+        assert tb.shape[0] < (B if L > 64 else -(-B // 2))
+        waves = np.zeros(B, dtype=np.int64)
+        for row in tb:
+            runs = [s for i, s in enumerate(row) if s >= 0 and (i == 0 or row[i - 1] != s)]
+            assert len(runs) == len(set(runs))           # the waves of a sequence are adjacent
+            for s in row[row >= 0]:
+                waves[s] += 1
+        assert (waves == np.maximum(1, -(-lens // 32))).all()     # every sequence once, with the waves its length needs
+        with torch.no_grad():
+            want, want_logits = bbg.run_forward(ids_d, t_d, km, want_hidden=True, want_logits=True)
+            got = torch.full_like(want, 7.0)
+            _, got_logits = bbg.run_forward(ids_d, t_d, km, want_hidden=True, want_logits=True, hidden_out=got,
+                                            wave_table=table)
+            only_logits = bbg.run_forward(ids_d, t_d, km, want_hidden=False, want_logits=True, wave_table=table)[1]
+        inside = torch.from_numpy(np.arange(L)[None] < (32 * waves)[:, None]).to(gpu_device)
+        assert torch.equal(got[inside], want[inside]), (L, B)
+        assert (got[~inside] == 7.0).all()
+        assert torch.equal(got_logits[inside], want_logits[inside])
+        assert torch.equal(only_logits[inside], want_logits[inside]) and (only_logits[~inside] == 0).all()
+    # a batch of full-length sequences gains nothing: no table
+    assert bbg.ragged_wave_table([128] * 16, 128, gpu_device) is None
+    with pytest.raises(ValueError, match="wave_table"):
+        bbg.run_forward(ids_d, t_d, km, wave_table=table.to(torch.int64))
+
+
 def test_cpu_tensors_fail_loudly():
     cfg, bb = tiny_model("tiny_h2")
     ids, attn, t = RI.backbone_inputs(cfg, 21)

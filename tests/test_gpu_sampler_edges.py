@@ -123,3 +123,33 @@ def test_samplers_on_the_medium_and_large_widths(gpu_device, variant, d, heads, 
     o, _ = replay(rec, tb, T, L, 1.0, True, fixed)
     of = ora.sample_fixup(tb, o["ids"], o["logits"], natural_eos=False, attn=o["attn"], has_eos=o["has_eos"])
     np.testing.assert_array_equal(out, of["ids"])
+
+
+@pytest.mark.parametrize("variant", ["smiles", "selfies", "group", "bpe"])
+def test_ragged_batches_sample_the_same_ids(gpu_device, variant):
+    """Per-sample lengths padded to the longest row: with the sequences dealt to the forward's waves by their own
+    lengths (the default) the samplers return the ids of the launch that computes every padded row."""
+    T, L = 8, 100
+    smp, tok = _sampler(variant, gpu_device, T)
+    rs = np.random.RandomState(11)
+    lengths = [int(x) for x in rs.randint(2, L + 1, size=45)]
+    lengths[3] = L
+    smp._core.seed = 31
+    assert smp._core.ragged is True
+    if variant in ("smiles", "bpe"):
+        run = lambda: smp.sample_with_lengths(lengths, max_length=L, show_progress=False)
+    else:
+        def run():
+            ids = torch.full((len(lengths), L), tok.pad_token_id, dtype=torch.long, device=gpu_device)
+            attn = torch.zeros_like(ids)
+            for i, n in enumerate(lengths):
+                ids[i, :n] = tok.mask_token_id
+                ids[i, 0] = tok.bos_token_id
+                ids[i, n - 1] = tok.eos_token_id
+                attn[i, :n] = 1
+            return smp._core.run(ids, attn, None), None
+    a, sa = run()
+    smp._core.ragged = False
+    b, sb = run()
+    assert torch.equal(a, b) and sa == sb
+    assert (a != tok.mask_token_id).all()
