@@ -432,6 +432,17 @@ class DiffusionBackbone(nn.Module):
         dev = device if device is not None else self.token_embedding.weight.device
         return torch.tensor(table, dtype=torch.int32).to(dev)
 
+    def wave_table_for_mask(self, mask):
+        """``ragged_wave_table`` for a [B, L] attention / key mask on the device (its last non-zero column + 1 is a
+        sequence's length; one device -> host copy), or None when nothing would be saved."""
+        B, L = mask.shape
+        if not (32 < L <= 128) or self.compute_dtype != "bf16" or B == 0:
+            return None
+        lens = ((mask != 0) * torch.arange(1, L + 1, device=mask.device)).amax(1)
+        if int(lens.min().item()) > (L - 1) // 32 * 32:          # nobody needs fewer waves than the padded length
+            return None
+        return self.ragged_wave_table(lens.tolist(), L, mask.device)
+
     def run_forward(self, input_ids, timesteps, keymask, want_hidden=True, want_logits=False,
                     hidden_out=None, logits_out=None, wave_table=None):
         """One inference forward on the current stream. keymask: uint8 [B,L] or None.
@@ -542,8 +553,18 @@ class DiffusionBackbone(nn.Module):
                 return (hs * m).sum(dim=1) / m.sum(dim=1).clamp(min=1e-9)
             return (hs * m + (1 - m) * (-1e9)).max(dim=1)[0]
         keymask = self._keymask_bytes(attention_mask, input_ids)
-        hidden, _ = self.run_forward(input_ids, timesteps, keymask, want_hidden=True, want_logits=False)
         B, L = input_ids.shape
+        # pooling under a mask reads attended rows only (and row 0): rows of 32-row blocks past a sequence's length are
+        # not computed, short sequences share workgroups of the forward (ragged_pooling = False: every padded row)
+        table = None
+        if attention_mask is not None and getattr(self, "ragged_pooling", True):
+            table = self.wave_table_for_mask(attention_mask)
+        if table is not None:
+            hidden = torch.zeros(B, L, self.hidden_size, dtype=torch.bfloat16, device=input_ids.device)
+            self.run_forward(input_ids, timesteps, keymask, want_hidden=True, want_logits=False, hidden_out=hidden,
+                             wave_table=table)
+        else:
+            hidden, _ = self.run_forward(input_ids, timesteps, keymask, want_hidden=True, want_logits=False)
         if self.compute_dtype == "fp32":        # the pooling kernel reads bf16 rows; fp32 rows are pooled by torch
             if pooling == "cls":
                 return hidden[:, 0, :].contiguous()

@@ -170,10 +170,8 @@ class ReverseSampler:
         # device -> host copy per call). Lengths only shrink during a run (natural EOS), so the table stays valid;
         # rows beyond a sequence's waves are never drawn, read or repaired, and stay zero.
         wave_table = None
-        if self.ragged and 32 < L <= 128 and hasattr(backbone, "ragged_wave_table"):
-            lens = ((attn != 0) * torch.arange(1, L + 1, device=dev)).amax(1)
-            if int(lens.min().item()) <= (L - 1) // 32 * 32:         # somebody needs fewer waves than the padded length
-                wave_table = backbone.ragged_wave_table(lens.tolist(), L, dev)
+        if self.ragged and hasattr(backbone, "wave_table_for_mask"):
+            wave_table = backbone.wave_table_for_mask(attn)
         hidden = (torch.zeros if wave_table is not None else torch.empty)(B, L, d, dtype=torch.bfloat16, device=dev)
         logits = None
         pk = backbone.packed()

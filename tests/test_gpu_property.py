@@ -109,6 +109,33 @@ def test_pooled_output_at_bench_shape_matches_oracle_and_guards(gpu_device):
             bb.get_pooled_output(ids.to(dev), t.to(dev), attn.to(dev), "median")
 
 
+def test_pooled_output_of_ragged_batches_skips_padded_blocks_with_the_same_bits(gpu_device):
+    """Under a mask the pooling reads attended rows only, so the forward computes just the 32-row blocks each
+    sequence needs (short sequences share workgroups): same pooled values, bit for bit, as with every padded row."""
+    from bidiff.model.backbone import DiffusionBackbone
+    cfg = dict(RI.SMALL_CFG, num_layers=2, dropout=0.0)
+    torch.manual_seed(6)
+    bb = DiffusionBackbone(**cfg).eval()
+    RI.perturb_state_dict(bb.state_dict(), 12)
+    bb = bb.to(gpu_device)
+    rs = np.random.RandomState(3)
+    B, L = 50, 120
+    lens = rs.randint(1, L + 1, size=B)
+    lens[0] = L
+    attn = torch.from_numpy((np.arange(L)[None] < lens[:, None]).astype(np.int64)).to(gpu_device)
+    ids = torch.from_numpy(rs.randint(5, cfg["vocab_size"], size=(B, L)).astype(np.int64)).to(gpu_device) * attn
+    t = torch.from_numpy(rs.randint(1, cfg["num_diffusion_steps"] + 1, size=B).astype(np.int64)).to(gpu_device)
+    assert bb.wave_table_for_mask(attn) is not None
+    for pooling in ("mean", "max", "cls"):
+        with torch.no_grad():
+            bb.ragged_pooling = True
+            a = bb.get_pooled_output(ids, t, attn, pooling)
+            bb.ragged_pooling = False
+            b = bb.get_pooled_output(ids, t, attn, pooling)
+        assert torch.isfinite(a).all() and torch.equal(a, b), pooling
+    bb.ragged_pooling = True
+
+
 @pytest.mark.parametrize("name,n_ft", [("tiny_h2", 1), ("tiny_h2", 2), ("tiny_h4", 1)])
 def test_finetune_last_layers_gradients_match_reference(gpu_device, name, n_ft):
     """PropertyPredictor(freeze_backbone=True, finetune_last_layers=N): the reference unfreezes the last N blocks
