@@ -317,6 +317,40 @@ def variant_bench(dev, variant, B, L, T, world, rank):
             "whole_path_tflops": fl / el / 1e12, "roofline": roofline_of(table), "kernels": named(table)}
 
 
+def ragged_bench(dev, B, T, mean_len=38):
+    """SMILES reverse sampling on per-sample lengths (log-normal around the training distribution's mean, clipped to
+    8..128, batch padded to 128) as the reference's step2 script draws them: sequences dealt to the forward's waves."""
+    import numpy as np
+    from bidiff import _lib
+    from bidiff.model.backbone import DiffusionBackbone
+    from bidiff.model.diffusion import DiscreteMaskingDiffusion
+    from bidiff.sampling.sampler import ConstrainedSampler
+    from bidiff.utils import synthetic
+    tok = synthetic.smiles_tokenizer()
+    torch.manual_seed(42)
+    bb = DiffusionBackbone(tok.vocab_size, 384, 6, 3, 1536, 256, T, 0.1, tok.pad_token_id)
+    model = DiscreteMaskingDiffusion(bb, num_steps=T, mask_token_id=tok.mask_token_id, pad_token_id=tok.pad_token_id,
+                                     bos_token_id=tok.bos_token_id, eos_token_id=tok.eos_token_id).to(dev).eval()
+    smp = ConstrainedSampler(model, tok, num_steps=T, temperature=1.0, use_constraints=True, device=str(dev))
+    smp._core.seed = 7
+    lengths = np.clip(np.random.RandomState(0).lognormal(np.log(mean_len), 0.45, size=B).astype(int), 8, 128).tolist()
+    lib = _lib.lib()
+    smp.sample_with_lengths(lengths, max_length=128, show_progress=False)
+    torch.cuda.synchronize()
+    prof_reset(lib)
+    t0 = time.perf_counter()
+    ids, _ = smp.sample_with_lengths(lengths, max_length=128, show_progress=False)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    table = prof_table(lib, 1e3 * el)
+    assert (ids != tok.mask_token_id).all()
+    return {"metric": "generated sequences/sec (Bi_Diffusion_SMILES reverse sampling, per-sample lengths)",
+            "value": B / el, "unit": "sequences/s (per GPU)", "ms_per_batch": 1e3 * el,
+            "config": {"workload": f"small backbone, batch {B} padded to {max(lengths)}, lengths mean "
+                                   f"{float(np.mean(lengths)):.1f}, T={T}, constraints on, decode included"},
+            "kernels": named(table)}
+
+
 def c5_bench(dev, B, L, T):
     """The stress configuration: 24 layers, d = 1024, ffn 4096, 8 heads of 128, L = 512."""
     from bidiff import _lib
@@ -458,6 +492,7 @@ def main():
                          ("smiles_bpe", lambda: variant_bench(dev, "bpe", B, L, 50, world, rank)),
                          # sequences of at most 64 tokens: two per workgroup of the single-launch forward
                          ("selfies_L64", lambda: variant_bench(dev, "selfies", B, 64, T, world, rank)),
+                         ("smiles_lengths_mean38", lambda: ragged_bench(dev, B, T)),
                          ("c5_24L_d1024_L512", lambda: c5_bench(dev, args.c5_batch, 512, T))):
             torch.cuda.empty_cache()
             try:
