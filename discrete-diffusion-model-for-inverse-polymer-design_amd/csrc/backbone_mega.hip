@@ -302,7 +302,9 @@ int mega_impl(const bd_backbone_desc* desc, const long long* ids, const long lon
   else if (dh == 64) rc = launch_mega<8, 64>(a, n_blocks, stream);
   else rc = launch_mega<8, 32>(a, n_blocks, stream);
   // algorithmic work of the layers: projections, attention products, feed-forward
-  if (tok) bd_prof_end(tok, stream, (double)c.n_layers * 2.0 * (double)B * L * (4.0 * d * d + 2.0 * L * d + 2.0 * d * c.ffn),
+  // (a launch on a wave table is charged the rows its workgroups hold, not the padded batch)
+  const double rows = wave_seq ? 128.0 * n_blocks : (double)B * L;
+  if (tok) bd_prof_end(tok, stream, (double)c.n_layers * 2.0 * rows * (4.0 * d * d + 2.0 * L * d + 2.0 * d * c.ffn),
                        BD_PROF_MEGA);
   return rc;
 }
