@@ -312,3 +312,26 @@ def plain_sample_step(model, noisy_ids, t, attention_mask, temperature):
     a.seq_offset = 0
     _lib.check(_lib.lib().bd_sample_step(C.byref(a), _lib.stream_handle()), "bd_sample_step")
     return ids
+
+
+def run_length_pieces(pieces, batch_size, run_lengths, offset0=0):
+    """Reverse loops for consecutive pieces (rows, length) of equal-length sequences, merged: up to ``batch_size``
+    rows of different lengths share one loop (``run_lengths(lengths, seq_offset) -> (ids, strings)``, a batch padded
+    to its longest row that the forward deals to its waves by length). Rows keep the global numbers they have when
+    every piece runs as a loop of its own, so with a fixed seed the results are the same. Returns the pieces' id
+    tensors [rows, length] and the strings of all rows in order."""
+    all_ids, all_strings, g, done = [], [], 0, int(offset0)
+    while g < len(pieces):
+        take, rows = [], 0
+        while g < len(pieces) and (not take or rows + pieces[g][0] <= batch_size):
+            take.append(pieces[g])
+            rows += pieces[g][0]
+            g += 1
+        ids, strings = run_lengths([ln for cur, ln in take for _ in range(cur)], done)
+        off = 0
+        for cur, ln in take:
+            all_ids.append(ids[off:off + cur, :ln].contiguous())
+            off += cur
+        all_strings.extend(strings)
+        done += rows
+    return all_ids, all_strings

@@ -118,13 +118,55 @@ class ConstrainedSampler:
         lo, hi = length_range
         inner = min(batch_size, samples_per_length)
         all_ids, all_strings = [], []
-        while len(all_strings) < num_samples:
-            cur = min(inner, num_samples - len(all_strings))
-            seq_length = int(np.random.randint(lo, hi + 1))
-            ids, s = self.sample(cur, seq_length, show_progress=False, seq_offset=len(all_strings))
-            all_ids.append(ids)
+        if not getattr(self, "merge_variable_length", True):
+            while len(all_strings) < num_samples:
+                cur = min(inner, num_samples - len(all_strings))
+                seq_length = int(np.random.randint(lo, hi + 1))
+                ids, s = self.sample(cur, seq_length, show_progress=False, seq_offset=len(all_strings))
+                all_ids.append(ids)
+                all_strings.extend(s)
+            return all_ids, all_strings
+        # The groups' lengths are drawn first (the same np.random calls in the same order); up to `batch_size` sequences
+        # of different lengths then share ONE reverse loop as a batch padded to its longest row (padding: PAD tokens
+        # outside the attention mask), which the forward deals to its waves by length instead of a launch of a handful
+        # of workgroups per group. With a fixed seed the rows are those of the group-by-group loop.
+        groups, n = [], 0
+        while n < num_samples:
+            cur = min(inner, num_samples - n)
+            groups.append((cur, int(np.random.randint(lo, hi + 1))))
+            n += cur
+        g = 0
+        while g < len(groups):
+            take, rows = [], 0
+            while g < len(groups) and (not take or rows + groups[g][0] <= batch_size):
+                take.append(groups[g])
+                rows += groups[g][0]
+                g += 1
+            ids, s = self._sample_lengths([ln for cur, ln in take for _ in range(cur)], seq_offset=len(all_strings))
+            off = 0
+            for cur, ln in take:
+                all_ids.append(ids[off:off + cur, :ln].contiguous())
+                off += cur
             all_strings.extend(s)
         return all_ids, all_strings
+
+    def _sample_lengths(self, lengths: List[int], seq_offset: int = 0):
+        """``sample`` for rows of different lengths in one batch: row i is BOS, lengths[i] - 2 masks, EOS, then PAD
+        outside the attention mask."""
+        self.diffusion_model.eval()
+        n, width = len(lengths), max(lengths)
+        lens = torch.tensor(lengths, dtype=torch.long)
+        pos = torch.arange(width).unsqueeze(0)
+        ids = torch.full((n, width), self.mask_id, dtype=torch.long)
+        ids[pos >= lens.unsqueeze(1)] = self.pad_id
+        ids[:, 0] = self.bos_id
+        ids[torch.arange(n), lens - 1] = self.eos_id
+        attn = (pos < lens.unsqueeze(1)).long()
+        self._core.num_steps = int(self.num_steps)
+        self._core.temperature = float(self.temperature)
+        self._core.use_constraints = bool(self.use_constraints)
+        ids = self._core.run(ids.to(self.device), attn.to(self.device), None, seq_offset=seq_offset)
+        return ids, decode_batch(self, ids)
 
     def _chemistry(self):
         """(count_stars, check_validity): caller-provided callables, else the host package's

@@ -159,11 +159,37 @@ class ConstrainedSampler:
         lo, hi = length_range
         inner = min(batch_size, samples_per_length)
         all_ids, all_smiles = [], []
-        while len(all_smiles) < num_samples:
-            cur = min(inner, num_samples - len(all_smiles))
-            seq_length = int(np.random.randint(lo, hi + 1))
-            ids, smiles = self.sample(cur, seq_length, show_progress=False, seq_offset=len(all_smiles))
-            all_ids.append(ids)
+        if not getattr(self, "merge_variable_length", True):
+            while len(all_smiles) < num_samples:
+                cur = min(inner, num_samples - len(all_smiles))
+                seq_length = int(np.random.randint(lo, hi + 1))
+                ids, smiles = self.sample(cur, seq_length, show_progress=False, seq_offset=len(all_smiles))
+                all_ids.append(ids)
+                all_smiles.extend(smiles)
+            return all_ids, all_smiles
+        # The reference runs one reverse loop per group of `samples_per_length` sequences (sampler.py:868-911): a
+        # handful of workgroups per launch. Here the groups' lengths are drawn first (the same np.random calls in the
+        # same order), and up to `batch_size` sequences of different lengths go through ONE loop as a batch padded to
+        # its longest row, the forward dealing them to its waves by length. A row's draws depend on its global number
+        # and its positions only, so with a fixed seed this returns what the group-by-group loop returns.
+        groups, n = [], 0
+        while n < num_samples:
+            cur = min(inner, num_samples - n)
+            groups.append((cur, int(np.random.randint(lo, hi + 1))))
+            n += cur
+        g = 0
+        while g < len(groups):
+            take, rows = [], 0
+            while g < len(groups) and (not take or rows + groups[g][0] <= batch_size):
+                take.append(groups[g])
+                rows += groups[g][0]
+                g += 1
+            lengths = [ln for cur, ln in take for _ in range(cur)]
+            ids, smiles = self.sample_with_lengths(lengths, show_progress=False, seq_offset=len(all_smiles))
+            off = 0
+            for cur, ln in take:
+                all_ids.append(ids[off:off + cur, :max(2, ln)].contiguous())
+                off += cur
             all_smiles.extend(smiles)
         return all_ids, all_smiles
 

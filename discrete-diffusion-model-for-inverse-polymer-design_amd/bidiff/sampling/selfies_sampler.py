@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from . import core
+from .core import run_length_pieces
 from .decode import decode_batch
 from .sampler import _progress
 
@@ -76,6 +77,25 @@ class ConstrainedSampler:
         strings = decode_batch(self, ids)
         return ids, strings
 
+    def _sample_lengths(self, lengths: List[int], seq_offset: int = 0):
+        """``sample`` (fixed final EOS) for rows of different lengths in one batch: row i is BOS, lengths[i] - 2
+        masks, EOS, then PAD outside the attention mask."""
+        self.diffusion_model.eval()
+        n, width = len(lengths), max(lengths)
+        lens = torch.tensor(lengths, dtype=torch.long)
+        pos = torch.arange(width).unsqueeze(0)
+        ids = torch.full((n, width), self.mask_id, dtype=torch.long)
+        ids[pos >= lens.unsqueeze(1)] = self.pad_id
+        ids[:, 0] = self.bos_id
+        ids[torch.arange(n), lens - 1] = self.eos_id
+        attn = (pos < lens.unsqueeze(1)).long()
+        self._core.num_steps = int(self.num_steps)
+        self._core.temperature = float(self.temperature)
+        self._core.use_constraints = bool(self.use_constraints)
+        ids = self._core.run(ids.to(self.device), attn.to(self.device), None, natural_eos=False, seq_offset=seq_offset,
+                             has_eos=torch.ones(n, dtype=torch.uint8, device=self.device))
+        return ids, decode_batch(self, ids)
+
     def sample_batch(self, num_samples: int, seq_length: int, batch_size: int = 256,
                      show_progress: bool = True, lengths: Optional[List[int]] = None):
         """Fixed-length batches, or - given ``lengths`` - one group of batches per distinct
@@ -92,6 +112,19 @@ class ConstrainedSampler:
         for i, ln in enumerate(lengths):
             groups[ln].append(i)
         result = [None] * len(lengths)
+        if getattr(self, "merge_variable_length", True):
+            # the same batches in the same order (one per distinct length and batch_size rows), but up to batch_size
+            # rows of different lengths share a reverse loop instead of one loop per distinct length
+            pieces, order = [], []
+            for ln in sorted(groups):
+                idxs = groups[ln]
+                order.extend(idxs)
+                for k in range(0, len(idxs), batch_size):
+                    pieces.append((min(batch_size, len(idxs) - k), int(ln)))
+            all_ids, strings = run_length_pieces(pieces, batch_size, self._sample_lengths)
+            for glob, st in zip(order, strings):
+                result[glob] = st
+            return all_ids, result
         done = 0
         for ln in sorted(groups):
             idxs = groups[ln]
@@ -112,6 +145,13 @@ class ConstrainedSampler:
         lo, hi = length_range
         inner = min(batch_size, samples_per_length)
         all_ids, all_strings = [], []
+        if getattr(self, "merge_variable_length", True):
+            pieces, n = [], 0                      # the groups' lengths first: same np.random calls, same order
+            while n < num_samples:
+                cur = min(inner, num_samples - n)
+                pieces.append((cur, int(np.random.randint(lo, hi + 1))))
+                n += cur
+            return run_length_pieces(pieces, batch_size, self._sample_lengths)
         while len(all_strings) < num_samples:
             cur = min(inner, num_samples - len(all_strings))
             ids, s = self.sample(cur, int(np.random.randint(lo, hi + 1)), show_progress=False,

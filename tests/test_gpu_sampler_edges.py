@@ -153,3 +153,43 @@ def test_ragged_batches_sample_the_same_ids(gpu_device, variant):
     b, sb = run()
     assert torch.equal(a, b) and sa == sb
     assert (a != tok.mask_token_id).all()
+
+
+@pytest.mark.parametrize("variant", ["smiles", "bpe", "group", "selfies"])
+def test_variable_length_groups_in_one_loop_equal_the_group_by_group_loop(gpu_device, variant):
+    """sample_variable_length draws the groups' lengths first and runs up to batch_size sequences of different
+    lengths through one reverse loop; with a fixed seed the ids and strings are those of the reference's shape of
+    the loop (one reverse loop per group of samples_per_length sequences, sampler.py:868-911)."""
+    T = 8
+    smp, tok = _sampler(variant, gpu_device, T)
+    smp._core.seed = 77
+    kw = dict(length_range=(20, 100), batch_size=64, samples_per_length=16, show_progress=False)
+    np.random.seed(9)
+    smp.merge_variable_length = True
+    a_ids, a_str = smp.sample_variable_length(150, **kw)
+    np.random.seed(9)
+    smp.merge_variable_length = False
+    b_ids, b_str = smp.sample_variable_length(150, **kw)
+    assert [tuple(x.shape) for x in a_ids] == [tuple(x.shape) for x in b_ids]
+    assert [x.shape[0] for x in a_ids] == [16] * 9 + [6] and len(a_str) == 150
+    for x, y in zip(a_ids, b_ids):
+        assert torch.equal(x, y)
+        assert (x != tok.mask_token_id).all() and (x[:, 0] == tok.bos_token_id).all() and (x[:, -1] == tok.eos_token_id).all()
+    assert a_str == b_str
+
+
+def test_selfies_batches_by_length_share_reverse_loops(gpu_device):
+    """SELFIES sample_batch(lengths=...) forms one group of batches per distinct length (reference SELFIES
+    sampler.py:421-502); here up to batch_size rows of different lengths share a loop. Same id tensors in the same
+    order and the same strings in the caller's order as the loop per distinct length, with a fixed seed."""
+    T = 8
+    smp, tok = _sampler("selfies", gpu_device, T)
+    smp._core.seed = 41
+    rs = np.random.RandomState(2)
+    lengths = [int(x) for x in rs.randint(12, 90, size=70)]
+    smp.merge_variable_length = True
+    a_ids, a_str = smp.sample_batch(70, 128, batch_size=32, show_progress=False, lengths=lengths)
+    smp.merge_variable_length = False
+    b_ids, b_str = smp.sample_batch(70, 128, batch_size=32, show_progress=False, lengths=lengths)
+    assert [tuple(x.shape) for x in a_ids] == [tuple(x.shape) for x in b_ids]
+    assert all(torch.equal(x, y) for x, y in zip(a_ids, b_ids)) and a_str == b_str and len(a_str) == 70
