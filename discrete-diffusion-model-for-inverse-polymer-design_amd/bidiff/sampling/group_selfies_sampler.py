@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from . import core
+from .core import run_length_pieces
 from .decode import decode_batch
 from .sampler import _progress
 
@@ -130,25 +131,12 @@ class ConstrainedSampler:
         # of different lengths then share ONE reverse loop as a batch padded to its longest row (padding: PAD tokens
         # outside the attention mask), which the forward deals to its waves by length instead of a launch of a handful
         # of workgroups per group. With a fixed seed the rows are those of the group-by-group loop.
-        groups, n = [], 0
+        pieces, n = [], 0
         while n < num_samples:
             cur = min(inner, num_samples - n)
-            groups.append((cur, int(np.random.randint(lo, hi + 1))))
+            pieces.append((cur, int(np.random.randint(lo, hi + 1))))
             n += cur
-        g = 0
-        while g < len(groups):
-            take, rows = [], 0
-            while g < len(groups) and (not take or rows + groups[g][0] <= batch_size):
-                take.append(groups[g])
-                rows += groups[g][0]
-                g += 1
-            ids, s = self._sample_lengths([ln for cur, ln in take for _ in range(cur)], seq_offset=len(all_strings))
-            off = 0
-            for cur, ln in take:
-                all_ids.append(ids[off:off + cur, :ln].contiguous())
-                off += cur
-            all_strings.extend(s)
-        return all_ids, all_strings
+        return run_length_pieces(pieces, batch_size, self._sample_lengths)
 
     def _sample_lengths(self, lengths: List[int], seq_offset: int = 0):
         """``sample`` for rows of different lengths in one batch: row i is BOS, lengths[i] - 2 masks, EOS, then PAD

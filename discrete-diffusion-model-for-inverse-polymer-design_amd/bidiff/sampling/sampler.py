@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from . import core
+from .core import run_length_pieces
 from .decode import decode_batch
 
 
@@ -172,26 +173,13 @@ class ConstrainedSampler:
         # same order), and up to `batch_size` sequences of different lengths go through ONE loop as a batch padded to
         # its longest row, the forward dealing them to its waves by length. A row's draws depend on its global number
         # and its positions only, so with a fixed seed this returns what the group-by-group loop returns.
-        groups, n = [], 0
+        pieces, n = [], 0
         while n < num_samples:
             cur = min(inner, num_samples - n)
-            groups.append((cur, int(np.random.randint(lo, hi + 1))))
+            pieces.append((cur, max(2, int(np.random.randint(lo, hi + 1)))))
             n += cur
-        g = 0
-        while g < len(groups):
-            take, rows = [], 0
-            while g < len(groups) and (not take or rows + groups[g][0] <= batch_size):
-                take.append(groups[g])
-                rows += groups[g][0]
-                g += 1
-            lengths = [ln for cur, ln in take for _ in range(cur)]
-            ids, smiles = self.sample_with_lengths(lengths, show_progress=False, seq_offset=len(all_smiles))
-            off = 0
-            for cur, ln in take:
-                all_ids.append(ids[off:off + cur, :max(2, ln)].contiguous())
-                off += cur
-            all_smiles.extend(smiles)
-        return all_ids, all_smiles
+        return run_length_pieces(pieces, batch_size, lambda lengths, off: self.sample_with_lengths(
+            lengths, show_progress=False, seq_offset=off))
 
     def sample_conditional(self, batch_size: int, seq_length: int,
                            prefix_ids: Optional[torch.Tensor] = None,
