@@ -226,6 +226,25 @@ def test_ragged_batches_deal_sequences_to_waves(gpu_device, hidden, heads, ffn):
         assert torch.equal(only_logits[inside], want_logits[inside]) and (only_logits[~inside] == 0).all()
     # a batch of full-length sequences gains nothing: no table
     assert bbg.ragged_wave_table([128] * 16, 128, gpu_device) is None
+    # the C entry point refuses a missing table, an empty one and lengths the single launch does not take
+    from bidiff import _lib
+    import ctypes as C
+    lib, pk = _lib.lib(), bbg.packed()
+    hid = torch.empty(B, L, hidden, dtype=torch.bfloat16, device=gpu_device)
+    args = lambda tab, nb, L_: (C.byref(pk.desc), _lib.ptr(ids_d), _lib.ptr(t_d), _lib.ptr(km), tab, nb, B, L_,
+                                _lib.ptr(hid), _lib.stream_handle())
+    assert lib.bd_backbone_mega_ragged(*args(None, 3, L)) != 0
+    assert b"wave table" in lib.bd_last_error()
+    assert lib.bd_backbone_mega_ragged(*args(_lib.ptr(table), 0, L)) != 0
+    assert lib.bd_backbone_mega_ragged(*args(_lib.ptr(table), int(table.shape[0]), 200)) != 0
+    assert b"unsupported" in lib.bd_last_error()
+    assert lib.bd_backbone_mega_ragged_supported(C.byref(pk.desc), 200) == 0
+    # table entries that name no sequence of the batch are treated as empty waves
+    bad = table.clone()
+    bad[0] = torch.tensor([-7, B, B + 5, 2 ** 30], dtype=torch.int32)
+    torch.cuda.synchronize()
+    assert lib.bd_backbone_mega_ragged(*args(_lib.ptr(bad), int(bad.shape[0]), L)) == 0
+    torch.cuda.synchronize()
     with pytest.raises(ValueError, match="wave_table"):
         bbg.run_forward(ids_d, t_d, km, wave_table=table.to(torch.int64))
 
