@@ -195,7 +195,9 @@ int bd_backbone_forward(const bd_backbone_desc* desc, const long long* ids,
                         void* workspace, long long workspace_bytes, void* hidden_out,
                         float* logits_out, void* stream);
 
-/* The same forward as ONE kernel launch, one sequence per workgroup, when bd_backbone_mega_supported
+/* The same forward as ONE kernel launch, one sequence per workgroup (two / four when L <= 64 / 32: the
+ * sequences sit side by side in the key tiles behind per-wave mask tables, rows keep their bits; environment
+ * BD_MEGA_PACK=0 turns the sharing off), when bd_backbone_mega_supported
  * (every layer carries the fused-kernel weight streams, L <= 128, n_layers <= 32): embeddings, all
  * layers and the final LayerNorm; the residual rows stay in registers from the embeddings to the
  * final LayerNorm. xbuf is not used any more (any non-null pointer; kept so that the signature
