@@ -82,7 +82,7 @@ class StepArgs(C.Structure):
         ("temperature", C.c_float),
         ("seed", C.c_ulonglong),
         ("seq_offset", C.c_longlong),
-        ("row_logits", VP), ("row_pos", VP), ("row_cap", C.c_int),
+        ("row_logits", VP), ("row_pos", VP), ("row_cap", C.c_int), ("rows_chosen", C.c_int),
     ]
 
 
@@ -183,11 +183,15 @@ SIGNATURES = {
     "bd_backbone_mega_ragged": (C.c_int, [C.POINTER(BackboneDesc), VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, VP, VP]),
     "bd_backbone_forward_ragged": (C.c_int, [C.POINTER(BackboneDesc), VP, VP, VP, VP, C.c_int, C.c_int, C.c_int,
                                              VP, C.c_longlong, VP, VP, VP]),
+    "bd_backbone_forward_rows_supported": (C.c_int, [C.POINTER(BackboneDesc), C.c_int]),
+    "bd_backbone_forward_rows": (C.c_int, [C.POINTER(BackboneDesc), VP, VP, VP, VP, C.c_int, C.c_int, C.c_int,
+                                           VP, VP, C.c_int, VP, C.c_longlong, VP, VP]),
     "bd_backbone_forward_layers": (C.c_int, [C.POINTER(BackboneDesc), VP, VP, VP, C.c_int, C.c_int, VP,
                                              C.c_longlong, C.c_int, VP, VP]),
     "bd_corrupt": (C.c_int, [VP, VP, VP, VP, C.c_int, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_int, C.c_int, C.c_ulonglong, C.c_longlong, VP]),
     "bd_sample_step": (C.c_int, [C.POINTER(StepArgs), VP]),
+    "bd_sample_choose_rows": (C.c_int, [C.POINTER(StepArgs), VP, VP, C.c_int, VP]),
     "bd_sample_fixup": (C.c_int, [C.POINTER(FixArgs), VP]),
     "bd_host_gumbel": (None, [VP, VP, C.c_longlong]),
     "bd_host_philox": (None, [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]),

@@ -488,6 +488,40 @@ class DiffusionBackbone(nn.Module):
         _lib.check(rc, "bd_backbone_forward")
         return (hidden_out if want_hidden else None), (logits_out if want_logits else None)
 
+    def rows_forward_supported(self, L) -> bool:
+        """Does ``run_forward_rows`` exist for this model and sequence length (the single-launch forward does)?"""
+        if self.compute_dtype != "bf16":
+            return False
+        return _lib.lib().bd_backbone_forward_rows_supported(C.byref(self.packed().desc), int(L)) == 1
+
+    def run_forward_rows(self, input_ids, timesteps, keymask, row_pos, need_all, row_cap, hidden_out, wave_table=None):
+        """The inference forward for a reverse step that reads few rows: ``hidden_out`` [B, L, d] bf16 receives the
+        final-norm rows at positions ``row_pos`` [B * row_cap] (int32, -1 = none) and every row of the sequences
+        flagged in ``need_all`` [B] (uint8); its other rows keep what they held (``bd_sample_choose_rows`` writes
+        both lists). The rows written equal ``run_forward``'s bit for bit."""
+        timesteps = self._check_inputs(input_ids, timesteps)
+        ids = input_ids.to(torch.long).contiguous()
+        B, L = ids.shape
+        pk = self.packed()
+        ws, need = self._workspace(pk, B, L, ids.device)
+        if hidden_out.dtype != torch.bfloat16 or not hidden_out.is_contiguous() or tuple(hidden_out.shape) != (B, L, self.hidden_size):
+            raise ValueError("hidden_out must be a contiguous bf16 [B, L, hidden] tensor")
+        if row_pos.dtype != torch.int32 or row_pos.numel() != B * row_cap or need_all.dtype != torch.uint8 \
+                or need_all.numel() != B:
+            raise ValueError("row_pos must be int32 [B * row_cap] and need_all uint8 [B]")
+        n_blocks = 0
+        if wave_table is not None:
+            if wave_table.dtype != torch.int32 or wave_table.dim() != 2 or wave_table.shape[1] != 4 \
+                    or not wave_table.is_contiguous() or wave_table.device != ids.device:
+                raise ValueError("wave_table must be a contiguous int32 [n_blocks, 4] tensor on the inputs' device")
+            n_blocks = int(wave_table.shape[0])
+        rc = _lib.lib().bd_backbone_forward_rows(
+            C.byref(pk.desc), _lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(keymask), _lib.ptr(wave_table), n_blocks,
+            B, L, _lib.ptr(row_pos), _lib.ptr(need_all), int(row_cap), _lib.ptr(ws), need, _lib.ptr(hidden_out),
+            _lib.stream_handle())
+        _lib.check(rc, "bd_backbone_forward_rows")
+        return hidden_out
+
     # ------------------------------------------------------------------ reference API
     def forward(self, input_ids: torch.Tensor, timesteps: torch.Tensor,
                 attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -128,6 +128,10 @@ class ReverseSampler:
         # Sequences shorter than the batch's padded length share workgroups of the single-launch forward (False: every
         # sequence computes all L rows, padding included).
         self.ragged = True
+        # The positions a step draws are chosen BEFORE its forward pass (the choice depends on the ids alone), and the
+        # forward finishes only those rows: the last feed-forward block and the final LayerNorm run for the chosen
+        # rows instead of all B * L (False: every step computes every hidden row). Same ids either way.
+        self.choose_first = True
 
     def _tables(self):
         if self._dt is None:
@@ -196,16 +200,22 @@ class ReverseSampler:
 
         use_rows = self.row_workspace if self.row_workspace is not None else tt.V > 128
         use_rows = bool(use_rows) and d in (128, 256, 384, 512)
-        if use_rows:
+        choose_first = (bool(self.choose_first) and getattr(backbone, "compute_dtype", "bf16") == "bf16"
+                        and hasattr(backbone, "run_forward_rows") and backbone.rows_forward_supported(L))
+        if use_rows or choose_first:
             # A sequence that starts with n masks draws about n / T of them per step (k = max(1, int(n_t / t)) keeps
-            # n_t near n t / T), at most ceil(L / T): the workspace covers that many rows per sequence, rounded up to
-            # a power of two; the rare draws beyond it compute their row one by one.
+            # n_t near n t / T), at most ceil(L / T): the row list covers that many rows per sequence, rounded up to
+            # a power of two; the rare draws beyond it compute their row one by one (and, with the rows chosen ahead
+            # of the forward, make it finish every row of their sequence).
             row_cap = 1
             while row_cap < min(self.row_cap_max, -(-L // self.num_steps)):
                 row_cap *= 2
+            row_pos = torch.empty(B * row_cap, dtype=torch.int32, device=dev)
+        if use_rows:
             vs = (tt.V + 31) // 32 * 32
             row_logits = torch.empty(B * row_cap, vs, dtype=torch.float32, device=dev)
-            row_pos = torch.empty(B * row_cap, dtype=torch.int32, device=dev)
+        if choose_first:
+            need_all = torch.empty(B, dtype=torch.uint8, device=dev)
 
         steps = range(self.num_steps, 0, -1)
         if progress is not None:
@@ -233,11 +243,17 @@ class ReverseSampler:
                 a.row_logits, a.row_pos, a.row_cap = None, None, 0
                 final_logits = logits
             else:
-                backbone.run_forward(ids, ts, keymask, want_hidden=True, want_logits=False, hidden_out=hidden,
-                                     **({} if wave_table is None else {"wave_table": wave_table}))
+                if choose_first:
+                    _lib.check(lib.bd_sample_choose_rows(C.byref(a), row_pos.data_ptr(), need_all.data_ptr(), row_cap,
+                                                         stream), "bd_sample_choose_rows")
+                    backbone.run_forward_rows(ids, ts, keymask, row_pos, need_all, row_cap, hidden, wave_table=wave_table)
+                else:
+                    backbone.run_forward(ids, ts, keymask, want_hidden=True, want_logits=False, hidden_out=hidden,
+                                         **({} if wave_table is None else {"wave_table": wave_table}))
                 a.hidden, a.wout = hidden.data_ptr(), pk.w_out.data_ptr()
                 if use_rows:
                     a.row_logits, a.row_pos, a.row_cap = row_logits.data_ptr(), row_pos.data_ptr(), row_cap
+                    a.rows_chosen = int(choose_first)
                 if dump is not None:
                     dump.zero_()
                     a.logits = dump.data_ptr()

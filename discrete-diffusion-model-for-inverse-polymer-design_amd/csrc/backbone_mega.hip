@@ -44,8 +44,53 @@ struct MegaArgs {
   int tables_by_dma;             // every bias table 16-byte aligned: fetched by LDS-DMA one phase ahead
   int seg_waves;                 // waves per sequence: 4, or 2 / 1 when L <= 64 / 32 (two / four sequences share a workgroup)
   const int* wave_seq;           // [gridDim.x, 4] sequence of each wave (-1: none), equal entries adjacent; null: the rule above
+  // Chosen-row mode (row_pos != null): the caller reads the hidden rows of row_pos[seq * row_cap + i] (positions, -1 =
+  // none) alone, unless need_all[seq] is set. A workgroup none of whose sequences needs all rows stops behind the last
+  // layer's attention phase and leaves the residual rows of the chosen positions in xsel[seq * row_cap + i, :]; the
+  // tail kernel runs the last feed-forward block and the final LayerNorm on those rows.
+  const int* row_pos;
+  const unsigned char* need_all;
+  float* xsel;
+  int row_cap;
   MegaLayer layers[MEGA_MAX_LAYERS];
 };
+
+// Final LayerNorm (affine) of the wave's 32 rows in accumulator layout -> the lane's half of its bf16 hidden row
+// (orow = start of the row, null: nothing stored).
+template <int NT>
+__device__ __forceinline__ void final_norm_store(const f32x16 (&acc)[NT / 2], const float* lnf_g, const float* lnf_b,
+                                                 float eps, unsigned short* orow, int h) {
+  constexpr int D = NT * 16;
+  constexpr int NT32 = NT / 2;
+  float s = 0.f;
+#pragma unroll
+  for (int T = 0; T < NT32; ++T)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[T][r];
+  s += __shfl_xor(s, 32, 64);
+  const float mean = s * (1.0f / D);
+  float q2 = 0.f;
+#pragma unroll
+  for (int T = 0; T < NT32; ++T)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const float dv = acc[T][r] - mean; q2 += dv * dv; }
+  q2 += __shfl_xor(q2, 32, 64);
+  const float rstd = rsqrtf(q2 * (1.0f / D) + eps);
+  if (orow != nullptr) {
+    unsigned short* o = orow + 4 * h;
+#pragma unroll
+    for (int T = 0; T < NT32; ++T)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 g = *(const f32x4*)(lnf_g + 32 * T + 8 * q + 4 * h);
+        const f32x4 b = *(const f32x4*)(lnf_b + 32 * T + 8 * q + 4 * h);
+        u32x2 w;
+        w[0] = bd_pack_bf16x2((acc[T][4 * q + 0] - mean) * rstd * g[0] + b[0], (acc[T][4 * q + 1] - mean) * rstd * g[1] + b[1]);
+        w[1] = bd_pack_bf16x2((acc[T][4 * q + 2] - mean) * rstd * g[2] + b[2], (acc[T][4 * q + 3] - mean) * rstd * g[3] + b[3]);
+        *(u32x2*)(o + 32 * T + 8 * q) = w;
+      }
+  }
+}
 
 template <int NT, int DH, int H>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void backbone_mega_kernel(MegaArgs p) {
@@ -71,6 +116,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int w = 1; w < 4; ++w) fw[w] = (sq[w] >= 0 && sq[w] == sq[w - 1]) ? fw[w - 1] : w;
   auto of_wave = [](const int (&a)[4], int w) { return w == 0 ? a[0] : w == 1 ? a[1] : w == 2 ? a[2] : a[3]; };
+  bool rows_only = p.row_pos != nullptr;         // workgroup-uniform: the last feed-forward block is the tail kernel's
+  if (rows_only) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+      if (sq[w] >= 0 && p.need_all[sq[w]] != 0) rows_only = false;
+  }
   const int seq_own = of_wave(sq, wave), first = of_wave(fw, wave);
   const int seq = seq_own >= 0 ? seq_own : 0;
   const int tok = 32 * (wave - first) + c;
@@ -155,12 +206,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const MegaLayer& lw = p.layers[l];
     ap.wpack = lw.attn_pack; ap.bq = lw.bq; ap.bo = lw.bo; ap.bo_fold = lw.bo_fold;
     fp.wpack = lw.ffn_pack; fp.b1 = lw.b1; fp.b2 = lw.b2;
+    const bool stop_here = rows_only && l + 1 == p.n_layers;
     // every wave has left the previous phase's LDS; no memory operation of this wave is pending
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (p.tables_by_dma) fetch_ffn_tables(lw);                 // nobody reads the feed-forward tables before the next barrier
+    if (p.tables_by_dma && !stop_here) fetch_ffn_tables(lw);   // nobody reads the feed-forward tables before the next barrier
     attn_phase<NT, DH, H>(ap, smem, acc);
+    if (p.row_pos != nullptr && l + 1 == p.n_layers && valid) {
+      // the residual rows of the chosen positions, as they stand behind the last attention block, for the tail kernel
+      // (also from a workgroup that goes on because another of its sequences needs every row: the tail kernel
+      // finishes the listed rows of every sequence that is not flagged itself, with the same bits)
+      int slot = -1;
+      for (int i = 0; i < p.row_cap; ++i)
+        if (p.row_pos[(size_t)seq * p.row_cap + i] == tok) slot = seq * p.row_cap + i;
+      if (slot >= 0) store_rows(acc, p.xsel + (size_t)slot * D + 4 * h);
+    }
+    if (stop_here) break;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -168,37 +230,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     ffn_phase<NT>(fp, smem, acc);
   }
 
+  if (rows_only) return;
+
   // ---- final LayerNorm (affine) -> bf16 hidden rows
-  {
-    float s = 0.f;
-#pragma unroll
-    for (int T = 0; T < NT32; ++T)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s += acc[T][r];
-    s += __shfl_xor(s, 32, 64);
-    const float mean = s * (1.0f / D);
-    float q2 = 0.f;
-#pragma unroll
-    for (int T = 0; T < NT32; ++T)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { const float dv = acc[T][r] - mean; q2 += dv * dv; }
-    q2 += __shfl_xor(q2, 32, 64);
-    const float rstd = rsqrtf(q2 * (1.0f / D) + p.eps);
-    if (valid) {
-      unsigned short* o = p.hidden + row * D + 4 * h;
-#pragma unroll
-      for (int T = 0; T < NT32; ++T)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 g = *(const f32x4*)(p.lnf_g + 32 * T + 8 * q + 4 * h);
-          const f32x4 b = *(const f32x4*)(p.lnf_b + 32 * T + 8 * q + 4 * h);
-          u32x2 w;
-          w[0] = bd_pack_bf16x2((acc[T][4 * q + 0] - mean) * rstd * g[0] + b[0], (acc[T][4 * q + 1] - mean) * rstd * g[1] + b[1]);
-          w[1] = bd_pack_bf16x2((acc[T][4 * q + 2] - mean) * rstd * g[2] + b[2], (acc[T][4 * q + 3] - mean) * rstd * g[3] + b[3]);
-          *(u32x2*)(o + 32 * T + 8 * q) = w;
-        }
-    }
+  final_norm_store<NT>(acc, p.lnf_g, p.lnf_b, p.eps, valid ? p.hidden + row * D : nullptr, h);
+}
+
+// The last feed-forward block and the final LayerNorm for the chosen rows that backbone_mega_kernel left in xsel
+// (chosen-row mode): 128 slots per workgroup, a wave = 32 slots, each an independent row (of any sequence). A row goes
+// through the same arithmetic as inside the single-launch kernel, so its hidden row carries the same bits.
+struct TailArgs {
+  const float* xsel;             // [n_slots, d] residual rows behind the last attention block
+  const int* row_pos;            // [n_slots] position inside sequence slot / row_cap, -1: empty slot
+  const unsigned char* need_all; // [B] sequences whose rows the main kernel finished itself
+  unsigned short* hidden;        // [B * L, d]
+  const float* lnf_g;
+  const float* lnf_b;
+  FfnPhase ph;
+  int n_slots, row_cap, L;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void mega_tail_kernel(TailArgs p) {
+  constexpr int D = NT * 16;
+  constexpr int NT32 = NT / 2;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, c = lane & 31;
+  const int slot = blockIdx.x * 128 + wave * 32 + c;
+  int pos = -1, b = 0;
+  if (slot < p.n_slots) {
+    b = slot / p.row_cap;
+    pos = p.need_all[b] != 0 ? -1 : p.row_pos[slot];
   }
+  if (!__syncthreads_or(pos >= 0)) return;
+  f32x16 acc[NT32];
+  {
+    const float* xrow = p.xsel + (size_t)(pos >= 0 ? slot : 0) * D + 4 * h;
+#pragma unroll
+    for (int T = 0; T < NT32; ++T)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = *(const f32x4*)(xrow + 32 * T + 8 * q);
+        if (pos < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};          // empty slots compute on zeros, not on stale memory
+        acc[T][4 * q + 0] = v[0]; acc[T][4 * q + 1] = v[1]; acc[T][4 * q + 2] = v[2]; acc[T][4 * q + 3] = v[3];
+      }
+#pragma unroll
+    for (int T = 0; T < NT32; ++T) asm volatile("" : "+a"(acc[T]));
+  }
+  ffn_phase<NT>(p.ph, smem, acc);
+  final_norm_store<NT>(acc, p.lnf_g, p.lnf_b, p.ph.eps, pos >= 0 ? p.hidden + ((size_t)b * p.L + pos) * D : nullptr, h);
 }
 
 template <int NT, int DH, int H = NT * 16 / DH>
@@ -220,6 +301,14 @@ int launch_mega(const MegaArgs& a, int n_blocks, hipStream_t stream) {
   BD_SET_MAX_LDS((backbone_mega_kernel<NT, DH, H>), lds);
   hipLaunchKernelGGL((backbone_mega_kernel<NT, DH, H>), dim3(blocks), dim3(256), lds, stream, b);
   return bd_check_launch("bd_backbone_mega");
+}
+
+template <int NT>
+int launch_tail(const TailArgs& t, hipStream_t stream) {
+  const size_t lds = ffn_phase_lds(NT, t.ph.F);
+  BD_SET_MAX_LDS((mega_tail_kernel<NT>), lds);
+  hipLaunchKernelGGL((mega_tail_kernel<NT>), dim3((t.n_slots + 127) / 128), dim3(256), lds, stream, t);
+  return bd_check_launch("bd_backbone_forward_rows (tail)");
 }
 
 }  // namespace
@@ -249,9 +338,17 @@ bool mega_tables_by_dma(const bd_backbone_desc& c) {
   return (bits & 15) == 0 && c.ffn % 4 == 0;
 }
 
+// Chosen rows of a launch (all null / 0: every row is computed)
+struct RowChoice {
+  const int* row_pos;
+  const unsigned char* need_all;
+  float* xsel;
+  int row_cap;
+};
+
 int mega_impl(const bd_backbone_desc* desc, const long long* ids, const long long* timesteps,
               const unsigned char* keymask, const int* wave_seq, int n_blocks, int B, int L, float* xbuf,
-              void* hidden_out, void* stream_) {
+              void* hidden_out, void* stream_, const RowChoice& rows_sel = RowChoice{nullptr, nullptr, nullptr, 0}) {
   hipStream_t stream = (hipStream_t)stream_;
   BD_REQUIRE(desc && ids && timesteps && hidden_out, "bd_backbone_mega: null operand");
   BD_REQUIRE(B > 0, "bd_backbone_mega: B=%d", B);
@@ -264,6 +361,7 @@ int mega_impl(const bd_backbone_desc* desc, const long long* ids, const long lon
   a.xbuf = xbuf; a.hidden = (unsigned short*)hidden_out;
   a.B = B; a.L = L; a.F = c.ffn; a.n_layers = c.n_layers; a.eps = c.ln_eps;
   a.wave_seq = wave_seq;
+  a.row_pos = rows_sel.row_pos; a.need_all = rows_sel.need_all; a.xsel = rows_sel.xsel; a.row_cap = rows_sel.row_cap;
   for (int i = 0; i < c.n_layers; ++i) {
     const bd_layer_weights& lw = c.layers[i];
     a.layers[i] = MegaLayer{(const unsigned char*)lw.attn_pack, lw.b_q_attn, lw.b_o, lw.b_o_fold,
@@ -304,9 +402,21 @@ int mega_impl(const bd_backbone_desc* desc, const long long* ids, const long lon
   // algorithmic work of the layers: projections, attention products, feed-forward
   // (a launch on a wave table is charged the rows its workgroups hold, not the padded batch)
   const double rows = wave_seq ? 128.0 * n_blocks : (double)B * L;
-  if (tok) bd_prof_end(tok, stream, (double)c.n_layers * 2.0 * rows * (4.0 * d * d + 2.0 * L * d + 2.0 * d * c.ffn),
+  // (chosen-row mode is charged without the last feed-forward block, which only sequences flagged need_all run)
+  const double ffn_flops = 2.0 * rows * 2.0 * d * c.ffn;
+  if (tok) bd_prof_end(tok, stream, (double)c.n_layers * 2.0 * rows * (4.0 * d * d + 2.0 * L * d + 2.0 * d * c.ffn) -
+                                        (rows_sel.row_pos ? ffn_flops : 0.0),
                        BD_PROF_MEGA);
-  return rc;
+  if (rc != BD_OK || rows_sel.row_pos == nullptr) return rc;
+  // the last feed-forward block and the final LayerNorm of the chosen rows
+  const bd_layer_weights& lw = c.layers[c.n_layers - 1];
+  TailArgs t{rows_sel.xsel, rows_sel.row_pos, rows_sel.need_all, (unsigned short*)hidden_out, c.lnf_g, c.lnf_b,
+             FfnPhase{(const unsigned char*)lw.ffn_pack, lw.b_fc1_ln, lw.b_fc2, c.ffn, c.ln_eps},
+             B * rows_sel.row_cap, rows_sel.row_cap, L};
+  bd_prof_scope prof(stream, 2.0 * 2.0 * (double)t.n_slots * d * c.ffn, BD_PROF_FFN);
+  if (d == 384) return launch_tail<24>(t, stream);
+  if (d == 256) return launch_tail<16>(t, stream);
+  return launch_tail<8>(t, stream);
 }
 }  // namespace
 
@@ -329,4 +439,28 @@ extern "C" int bd_backbone_mega_ragged(const bd_backbone_desc* desc, const long 
   BD_REQUIRE(wave_seq != nullptr && n_blocks > 0, "bd_backbone_mega_ragged: no wave table");
   BD_REQUIRE(desc && bd_backbone_mega_ragged_supported(desc, L), "bd_backbone_mega_ragged: unsupported model shape or L=%d", L);
   return mega_impl(desc, ids, timesteps, keymask, wave_seq, n_blocks, B, L, nullptr, hidden_out, stream);
+}
+
+extern "C" int bd_backbone_forward_rows_supported(const bd_backbone_desc* c, int L) {
+  return bd_backbone_mega_supported(c, L);
+}
+
+extern "C" int bd_backbone_forward_rows(const bd_backbone_desc* desc, const long long* ids, const long long* timesteps,
+                                        const unsigned char* keymask, const int* wave_seq, int n_blocks, int B, int L,
+                                        const int* row_pos, const unsigned char* need_all, int row_cap,
+                                        void* workspace, long long workspace_bytes, void* hidden_out, void* stream) {
+  BD_REQUIRE(desc && row_pos && need_all && workspace && hidden_out, "bd_backbone_forward_rows: null operand");
+  BD_REQUIRE(B > 0 && L > 0, "bd_backbone_forward_rows: empty batch");
+  BD_REQUIRE(row_cap >= 1 && row_cap <= 32, "bd_backbone_forward_rows: row_cap=%d outside 1..32", row_cap);
+  BD_REQUIRE((long long)B * row_cap < (1ll << 31) / desc->d, "bd_backbone_forward_rows: too many row slots");
+  BD_REQUIRE(workspace_bytes >= (long long)B * row_cap * desc->d * 4,
+             "bd_backbone_forward_rows: workspace %lld < %lld bytes", workspace_bytes, (long long)B * row_cap * desc->d * 4);
+  BD_REQUIRE(((size_t)workspace & 15) == 0, "bd_backbone_forward_rows: workspace must be 16-byte aligned");
+  if (wave_seq != nullptr) {
+    BD_REQUIRE(n_blocks > 0, "bd_backbone_forward_rows: wave table without workgroups");
+    BD_REQUIRE(bd_backbone_mega_ragged_supported(desc, L), "bd_backbone_forward_rows: unsupported model shape or L=%d for a wave table", L);
+  }
+  BD_REQUIRE(bd_backbone_forward_rows_supported(desc, L), "bd_backbone_forward_rows: unsupported model shape or L=%d", L);
+  return mega_impl(desc, ids, timesteps, keymask, wave_seq, n_blocks, B, L, nullptr, hidden_out, stream,
+                   RowChoice{row_pos, need_all, (float*)workspace, row_cap});
 }

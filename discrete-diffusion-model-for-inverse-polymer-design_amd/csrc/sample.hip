@@ -177,20 +177,34 @@ __device__ __forceinline__ int choose_positions(const bd_step_args& p, const Sme
 // projection for every row it draws (V * d * 2 bytes each: 617 KB at V = 803, d = 384).
 
 // row_pos[b * cap + i] = position of sequence b's i-th draw of this step, or -1.
-__global__ __launch_bounds__(64) void choose_rows_kernel(bd_step_args p) {
+// need_all (optional) [B]: 1 when the step reads hidden rows of sequence b beyond those: more draws than row_cap, or
+// the urgency rule, which reads the boosted token's logit at every position (the condition of sample_step_kernel).
+__global__ __launch_bounds__(64) void choose_rows_kernel(bd_step_args p, unsigned char* need_all) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem s;
   const int lane = threadIdx.x, b = blockIdx.x, L = p.L;
   smem_carve(s, smem_raw, L, p.V, p.d, p.R > 0 ? p.R : 1);
   load_ids_and_flags(p, s, b, lane);
-  int n_sel = 0;
+  int n_sel = 0, n_mask = 0, total = 0;
   for (int l = lane; l < L; l += 64) {
     const int f = s.pf[l];
     n_sel += (f & PF_MASK0) && !(f & PF_FIXED);
+    if (f & PF_MASK0) n_mask++;
+    else total += p.contrib[s.ids[l]];
   }
   n_sel = bd_wave_sum_i(n_sel);
   const int k_sel = choose_positions(p, s, b, lane, n_sel);
   for (int i = lane; i < p.row_cap; i += 64) p.row_pos[(size_t)b * p.row_cap + i] = i < k_sel ? (int)s.sel[i] : -1;
+  if (need_all != nullptr) {
+    n_mask = bd_wave_sum_i(n_mask);
+    total = bd_wave_sum_i(total);
+    bool all = k_sel > p.row_cap;
+    if (p.use_constraints && (p.variant & BD_VB_URGENCY)) {
+      const int needed = 2 - total;
+      if (needed > 0 && n_mask > 0 && n_mask <= 5 * needed) all = true;
+    }
+    if (lane == 0) need_all[b] = all ? 1 : 0;
+  }
 }
 
 // row_logits[slot][v] = hidden[b, row_pos[slot], :] . wout[v, :] for the occupied slots. A workgroup = 4 waves =
@@ -846,7 +860,8 @@ extern "C" int bd_sample_step(const bd_step_args* a, void* stream) {
                "bd_sample_step: row_cap=%d is not a power of two in 1..32", p.row_cap);
     BD_REQUIRE(p.d % 16 == 0 && p.d <= 512 && (p.d / 16) % 8 == 0,
                "bd_sample_step: the chosen-row workspace needs d in {128, 256, 384, 512}, not %d", p.d);
-    hipLaunchKernelGGL(choose_rows_kernel, dim3(p.B), dim3(64), lds, (hipStream_t)stream, p);
+    if (!p.rows_chosen)
+      hipLaunchKernelGGL(choose_rows_kernel, dim3(p.B), dim3(64), lds, (hipStream_t)stream, p, (unsigned char*)nullptr);
     const dim3 grid((unsigned)(((long long)p.B * p.row_cap + 127) / 128), 4);
 #define BD_ROWS(NK)                                                                            \
   do {                                                                                         \
@@ -864,6 +879,27 @@ extern "C" int bd_sample_step(const bd_step_args* a, void* stream) {
   }
   hipLaunchKernelGGL(sample_step_kernel, dim3(p.B), dim3(64), lds, (hipStream_t)stream, p, VS);
   return bd_check_launch("bd_sample_step");
+}
+
+extern "C" int bd_sample_choose_rows(const bd_step_args* a, int* row_pos, unsigned char* need_all, int row_cap,
+                                     void* stream) {
+  BD_REQUIRE(a != nullptr && row_pos != nullptr && need_all != nullptr, "bd_sample_choose_rows: null operand");
+  bd_step_args p = *a;
+  BD_REQUIRE(p.ids && p.ktable && p.contrib, "bd_sample_choose_rows: null table or ids");
+  BD_REQUIRE(p.B >= 0 && p.L > 0 && p.L <= MAXL, "bd_sample_choose_rows: L=%d outside 1..%d", p.L, MAXL);
+  BD_REQUIRE(p.V > 0 && p.V <= MAXV, "bd_sample_choose_rows: V=%d outside 1..%d", p.V, MAXV);
+  BD_REQUIRE(p.R >= 0 && p.R <= MAXR, "bd_sample_choose_rows: %d ring ids > %d", p.R, MAXR);
+  BD_REQUIRE(p.d > 0 && p.d <= MAXD, "bd_sample_choose_rows: d=%d unsupported", p.d);
+  BD_REQUIRE(p.t >= 1, "bd_sample_choose_rows: t must be >= 1");
+  BD_REQUIRE(row_cap >= 1 && row_cap <= 32, "bd_sample_choose_rows: row_cap=%d outside 1..32", row_cap);
+  if (p.B == 0) return BD_OK;
+  p.row_pos = row_pos;
+  p.row_cap = row_cap;
+  const size_t lds = smem_bytes(p.L, p.V, p.d, p.R > 0 ? p.R : 1);
+  BD_REQUIRE(lds <= 64 * 1024, "bd_sample_choose_rows: working set of %zu bytes per sequence exceeds LDS", lds);
+  bd_prof_scope prof(stream, (double)p.B * (9.0 * p.L + 4.0 * row_cap + 1.0), BD_PROF_SAMPLE);
+  hipLaunchKernelGGL(choose_rows_kernel, dim3(p.B), dim3(64), lds, (hipStream_t)stream, p, need_all);
+  return bd_check_launch("bd_sample_choose_rows");
 }
 
 extern "C" int bd_sample_fixup(const bd_fix_args* a, void* stream) {

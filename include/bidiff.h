@@ -225,6 +225,22 @@ int bd_backbone_forward_ragged(const bd_backbone_desc* desc, const long long* id
                                void* workspace, long long workspace_bytes, void* hidden_out, float* logits_out,
                                void* stream);
 
+/* The forward for a reverse step that reads few hidden rows: hidden_out [B*L, d] bf16 receives the final-norm rows
+ * of the positions row_pos[b * row_cap + i] (>= 0) of every sequence b, and all rows of the sequences with
+ * need_all[b] != 0 (bd_sample_choose_rows writes both); any other row of hidden_out either keeps what it held
+ * or receives its final-norm row too (the rows of a sequence that shares a workgroup with a flagged one). The
+ * rows written carry the bits bd_backbone_mega writes. Every layer runs for every row except the last
+ * feed-forward block and the final LayerNorm, which only the listed rows need (the last layer's keys and
+ * values need every row of the layers below).
+ * wave_seq / n_blocks: as for bd_backbone_mega_ragged, or null / 0. workspace: B * row_cap * d floats.
+ * Serves the reverse loop at t > 1 (src/sampling/sampler.py:661-718: the step reads the logits of the positions
+ * it draws, :686-693; their choice does not depend on the logits, :676-686). */
+int bd_backbone_forward_rows_supported(const bd_backbone_desc* desc, int L);
+int bd_backbone_forward_rows(const bd_backbone_desc* desc, const long long* ids, const long long* timesteps,
+                             const unsigned char* keymask, const int* wave_seq, int n_blocks, int B, int L,
+                             const int* row_pos, const unsigned char* need_all, int row_cap,
+                             void* workspace, long long workspace_bytes, void* hidden_out, void* stream);
+
 /* Embeddings + the first n_run blocks only; resid_out [B*L, d] fp32 receives the residual stream
  * (no final LayerNorm). Replaces get_hidden_states(layer_idx = n_run - 1 >= 0),
  * src/model/backbone.py:259-299. */
@@ -586,6 +602,8 @@ typedef struct bd_step_args {
   float* row_logits;            /* [B * row_cap, (V + 31) / 32 * 32] or null                           */
   int* row_pos;                 /* [B * row_cap]                                                        */
   int row_cap;
+  int rows_chosen;              /* non-zero: row_pos already holds this step's choice (bd_sample_choose_rows ran
+                                   on these ids with this row_cap); zero: bd_sample_step fills it itself  */
 } bd_step_args;
 
 /* One reverse step t for a batch: static constraints, choice of k positions per sequence,
@@ -595,6 +613,16 @@ typedef struct bd_step_args {
  * Bi_Diffusion_SELFIES/src/sampling/sampler.py:306-393,
  * Bi_Diffusion_Group_SELFIES/src/sampling/sampler.py:363-418. */
 int bd_sample_step(const bd_step_args* args, void* stream);
+
+/* The positions step t will draw, known before the forward pass of that step: row_pos[b * row_cap + i] = position
+ * of sequence b's i-th draw (draw order), -1 past its last draw. need_all[b] = 1 when the step reads hidden rows of
+ * sequence b beyond those (it draws more than row_cap positions, or the SELFIES urgency rule applies, which reads the
+ * placeholder logit of every position), else 0. Reads args->ids, fixed, ktable, contrib, u_sel / seed, seq_offset,
+ * t, variant, use_constraints and the token ids; row_pos / row_cap of the struct are ignored.
+ * The reference chooses with torch.randperm after the forward, from ids the forward does not change:
+ * src/sampling/sampler.py:676-686 (the choice does not depend on the logits),
+ * Bi_Diffusion_SELFIES/src/sampling/sampler.py:133-152 (urgency condition). */
+int bd_sample_choose_rows(const bd_step_args* args, int* row_pos, unsigned char* need_all, int row_cap, void* stream);
 
 typedef struct bd_fix_args {
   long long* ids;               /* [B,L] in/out                                             */
