@@ -198,6 +198,7 @@ SIGNATURES = {
     "bd_host_dropout_factors": (C.c_int, [VP, C.c_uint, C.c_longlong, C.c_longlong, VP]),
     "bd_host_uniform_select": (C.c_float, [C.c_ulonglong, C.c_uint32, C.c_uint32, C.c_uint32]),
     "bd_host_uniform_token": (C.c_float, [C.c_ulonglong, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "bd_clock_stamps_set": (C.c_int, [VP, C.c_int]),
     "bd_prof_enable": (C.c_int, [C.c_int]),
     "bd_prof_read": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
     "bd_prof_read_kind": (C.c_int, [C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),

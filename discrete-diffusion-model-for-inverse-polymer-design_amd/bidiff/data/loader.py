@@ -11,6 +11,9 @@ import torch
 from .. import _lib
 
 
+ROW_LENGTHS_KEY = "bidiff_row_lengths"
+
+
 class DeviceBatchLoader:
     def __init__(self, store, batch_sampler, device, pad_to_max_length: bool = False):
         self.store, self.batch_sampler = store, batch_sampler
@@ -47,8 +50,10 @@ class DeviceBatchLoader:
                                          self.store.pad_token_id, _lib.ptr(ids), _lib.ptr(mask), _lib.ptr(self._err),
                                          _lib.stream_handle())
         _lib.check(rc, "bd_collate_batch")
-        # "lengths" (host integers) lets the training step lay out its packed rows without a device round trip
-        return {"input_ids": ids, "attention_mask": mask, "lengths": np.minimum(self.store.lengths[idx], L)}
+        # ROW_LENGTHS_KEY (host integers: last attended position + 1 of every row, exactly what the mask says) lets the
+        # training step lay out its packed rows without a device round trip. The key is this package's own: a
+        # "lengths" entry of some other data set may mean something else and is never read by the trainer.
+        return {"input_ids": ids, "attention_mask": mask, ROW_LENGTHS_KEY: np.minimum(self.store.lengths[idx], L)}
 
     def _upload_indices(self, idx, B):
         if len(self._ring) < self.ring_slots:

@@ -73,6 +73,26 @@ class TransformerBlock(nn.Module):
         return block_forward(self, x, attention_mask)
 
 
+F16_MAX = 65504.0
+F16_MIN_NORMAL = 2.0 ** -14
+
+
+def _fits_f16_feed_forward(w1ln, b1ln, w2, d) -> bool:
+    """May a layer's feed-forward block run in the fused kernel, whose GELU and second product are f16?
+
+    The first product's outputs must stay inside f16: a LayerNorm output row has norm <= sqrt(d), so
+    |fc1 output j| <= |row j of W1 * gamma| * sqrt(d) + |bias j|, and the largest such bound must be below 65504 (past it
+    the packed conversion saturates and GELU(x) stops growing with x). W2 is stored as f16 there: exact for bf16
+    values of normal f16 size, while entries below 2^-14 = 6.1e-5 lose bits (counted as lost altogether here); a row
+    may lose at most 2^-9 of its absolute sum that way, the rounding bf16 itself brings. One device -> host copy per
+    layer, when the weights are packed."""
+    bound = w1ln.float().norm(dim=1) * math.sqrt(d) + b1ln.float().abs()
+    w = w2.detach().to(torch.bfloat16).float().abs()
+    lost = torch.where((w < F16_MIN_NORMAL) | (w > F16_MAX), w, torch.zeros_like(w)).sum(dim=1)
+    ok = (bound.max() < F16_MAX) & torch.isfinite(w).all() & (lost <= w.sum(dim=1) * 2.0 ** -9).all()
+    return bool(ok.item())
+
+
 class _Packed:
     """bf16 copies of the matrices + the C descriptor pointing at them."""
 
@@ -275,8 +295,11 @@ class DiffusionBackbone(nn.Module):
                 w1ln = bf(w1 * blk.norm2.weight.float()[None, :])
                 lw.w_fc1_ln = w1ln.data_ptr()
                 lw.b_fc1_ln = f32(blk.ffn.fc1.bias.float() + w1 @ blk.norm2.bias.float()).data_ptr()
-                # weight stream of the fused feed-forward kernel (fragment order, see ffn_fused.hip)
-                if L_.bd_ffn_fused_supported(d, F):
+                # weight stream of the fused feed-forward kernel (fragment order, see ffn_fused.hip); it computes GELU
+                # and the second product in f16, which not every weight set fits: such layers keep the bf16 kernels
+                if L_.bd_ffn_fused_supported(d, F) and _fits_f16_feed_forward(w1 * blk.norm2.weight.float()[None, :],
+                                                                           blk.ffn.fc1.bias.float() + w1 @ blk.norm2.bias.float(),
+                                                                           blk.ffn.fc2.weight, d):
                     pack = torch.empty(L_.bd_ffn_pack_bytes(d, F), dtype=torch.uint8, device=dev)
                     keep.append(pack)
                     _lib.check(L_.bd_ffn_pack_weights(w1ln.data_ptr(), lw.w_fc2, pack.data_ptr(), d, F,

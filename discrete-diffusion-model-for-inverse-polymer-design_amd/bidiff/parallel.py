@@ -36,16 +36,23 @@ class GradientExchange:
     the tail ``flat[split:]`` (upper layers, final norm, vocabulary head) is complete when the backward pass has
     left layer ``split_layer``. ``tail_ready()`` is called at that point (by the backward pass, on the stream whose
     work completes the tail) and starts an asynchronous all-reduce of the tail; ``finish()`` reduces the head,
-    waits for both and divides by the world size. If ``tail_ready`` was never called (accumulated gradients handed
-    to autograd, a backward pass without the hook) ``finish`` reduces the whole buffer in one call. Skipping both on
-    accumulation micro-steps is the reference's ``no_sync`` (:427-431)."""
+    waits for both and divides by the world size. Every rank issues the SAME collectives in the same order whatever
+    its backward pass did: with a split inside the buffer always the tail's all-reduce, then the head's (if
+    ``tail_ready`` was not called before ``finish`` - accumulated gradients handed to autograd, a backward pass
+    without the hook - ``finish`` issues the tail's itself); without a split one all-reduce of the whole buffer.
+    Which of the two it is depends on ``split`` alone, a fact of the model's layout that all ranks share, so ranks
+    cannot meet in collectives of different sizes. Skipping everything on accumulation micro-steps is the
+    reference's ``no_sync`` (:427-431). Not yet run with more than one RCCL rank on hardware
+    (``BD_OVERLAP_ALLREDUCE=0`` keeps the single blocking all-reduce)."""
 
     def __init__(self, flat: torch.Tensor, split: int, world_size: int):
         if not (0 <= split <= flat.numel()):
             raise ValueError("GradientExchange: split outside the buffer")
         self.flat, self.split, self.world = flat, int(split), int(world_size)
+        self.two_buckets = 0 < self.split < flat.numel()
         self._tail = None
         self.armed = False
+        self.early_tails = 0          # how many steps started their tail from the backward pass (diagnostics)
 
     def _on(self):
         return self.world > 1 and dist.is_available() and dist.is_initialized()
@@ -56,17 +63,20 @@ class GradientExchange:
         self._tail = None
 
     def tail_ready(self):
-        if not self.armed or self._tail is not None or not self._on() or self.split >= self.flat.numel() or self.split == 0:
+        if not self.armed or self._tail is not None or not self._on() or not self.two_buckets:
             return
         self._tail = dist.all_reduce(self.flat[self.split:], op=dist.ReduceOp.SUM, async_op=True)
+        self.early_tails += 1
 
     def finish(self):
         self.armed = False
         if not self._on():
             return self.flat
-        if self._tail is None:
+        if not self.two_buckets:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         else:
+            if self._tail is None:     # the backward pass did not reach the hook: same two collectives, same order
+                self._tail = dist.all_reduce(self.flat[self.split:], op=dist.ReduceOp.SUM, async_op=True)
             dist.all_reduce(self.flat[:self.split], op=dist.ReduceOp.SUM)
             self._tail.wait()          # the current stream waits for the tail's collective
             self._tail = None

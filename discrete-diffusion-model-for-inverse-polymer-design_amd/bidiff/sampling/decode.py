@@ -7,12 +7,23 @@ only slices one byte buffer into B strings. It applies to tokenizers whose decod
 non-special tokens (SMILES, SMILES_BPE, SELFIES); ``for_tokenizer`` checks that on probe rows against the
 tokenizer's own ``batch_decode`` and returns None otherwise (Group SELFIES, whose detokenize runs the group
 grammar on the host)."""
+import logging
+import warnings
 from typing import List, Optional
 
 import numpy as np
 import torch
 
 from .. import _lib
+
+_HOST_DECODE_LOGGED = set()
+
+
+def _log_host_decode_once(name):
+    """One line per tokenizer class whose decode is not the plain join (its own batch_decode keeps running on the host)."""
+    if name not in _HOST_DECODE_LOGGED:
+        _HOST_DECODE_LOGGED.add(name)
+        logging.getLogger("bidiff").info("decode of %s stays on the host: not a plain join of the token texts", name)
 
 
 class DeviceDecoder:
@@ -41,11 +52,16 @@ class DeviceDecoder:
         V = int(tokenizer.vocab_size)
         special = set(special)
         plain = lambda row: "".join(t for t in (id_to_token.get(int(i), "[UNK]") for i in row) if t not in special)
-        probes = [list(range(V)), list(range(V - 1, -1, -1)), [V + 3, 0, 1, 2, 3, 4 % V, V - 1, V - 1], []]
+        # probe rows of ids the tokenizer knows (an id outside 0..V-1 decodes to nothing in the kernel; what a
+        # tokenizer does with one - skip it, print [UNK], raise - is its own business and no sampler produces one)
+        probes = [list(range(V)), list(range(V - 1, -1, -1)), [0, 1, 2, 3, 4 % V, V - 1, V - 1], []]
         try:
-            if tokenizer.batch_decode(probes, skip_special_tokens=True) != [plain(r) for r in probes]:
-                return None
-        except Exception:
+            same = tokenizer.batch_decode(probes, skip_special_tokens=True) == [plain(r) for r in probes]
+        except Exception as exc:       # a tokenizer that cannot decode its own vocabulary: say so once, decode on the host
+            warnings.warn(f"bidiff: device decode disabled, the tokenizer's batch_decode raised on probe rows: {exc!r}")
+            return None
+        if not same:
+            _log_host_decode_once(type(tokenizer).__name__)
             return None
         return cls(id_to_token, special, V, device)
 
@@ -69,9 +85,11 @@ class DeviceDecoder:
 def decode_batch(owner, ids: torch.Tensor) -> List[str]:
     """``owner.tokenizer.batch_decode(ids, skip_special_tokens=True)``, on the device when the tokenizer's decode
     is the plain join (decided once per owner), through the tokenizer itself otherwise."""
+    if not ids.is_cuda:               # nothing is decided (or remembered) from host tensors
+        return owner.tokenizer.batch_decode(ids.tolist(), skip_special_tokens=True)
     dec = getattr(owner, "_device_decoder", False)
     if dec is False:
-        dec = DeviceDecoder.for_tokenizer(owner.tokenizer, ids.device) if ids.is_cuda else None
+        dec = DeviceDecoder.for_tokenizer(owner.tokenizer, ids.device)
         owner._device_decoder = dec
     if dec is None:
         return owner.tokenizer.batch_decode(ids.cpu().tolist(), skip_special_tokens=True)

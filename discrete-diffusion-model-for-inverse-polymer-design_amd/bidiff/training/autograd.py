@@ -49,8 +49,22 @@ def _side_stream(dev):
 _TAIL_HOOK = [None, -1]
 
 
-def set_tail_ready_hook(fn, layer_index: int = -1):
+def set_tail_ready_hook(fn, layer_index: int = -1, model=None):
+    """``model`` (a DiffusionBackbone): the hook belongs to that backbone's backward passes alone, so a second trainer
+    or a property head fine-tuning another backbone in the same process neither inherits nor overwrites it
+    (``fn = None`` removes it). Without ``model`` the hook applies to every backbone that has none of its own."""
+    if model is not None:
+        if fn is None:
+            model.__dict__.pop("_tail_ready_hook", None)
+        else:
+            model.__dict__["_tail_ready_hook"] = (fn, int(layer_index))
+        return
     _TAIL_HOOK[0], _TAIL_HOOK[1] = fn, int(layer_index)
+
+
+def _tail_hook_of(model):
+    own = model.__dict__.get("_tail_ready_hook")
+    return own if own is not None else (_TAIL_HOOK[0], _TAIL_HOOK[1])
 
 
 def _ck(rc, what):
@@ -555,6 +569,8 @@ class _BackboneFn(torch.autograd.Function):
             done.record(side)
             handed[li] = done
 
+        hook_fn, hook_layer = _tail_hook_of(model)
+
         def tail_hook(li):
             """Every gradient of the layers >= li is enqueued (main stream: this layer's kernels; second stream: the
             weight-gradient GEMMs handed over so far): un-pad the upper layers' attention gradients, then call the hook
@@ -572,7 +588,7 @@ class _BackboneFn(torch.autograd.Function):
             finally:
                 _STREAM[0] = main_h
             with torch.cuda.stream(side if side is not None else main):
-                _TAIL_HOOK[0]()
+                hook_fn()
 
         def wgrad_side(li, dY, X, dW, N, K, db):
             if side is None:
@@ -648,7 +664,7 @@ class _BackboneFn(torch.autograd.Function):
                     drop_dx=embed_drop_done, parts=lnp)
             if side is not None:
                 hand_over(li)
-            if direct and _TAIL_HOOK[0] is not None and li == _TAIL_HOOK[1]:
+            if direct and hook_fn is not None and li == hook_layer:
                 tail_hook(li)
         if need_embed and drop is not None and not embed_drop_done:
             _ck(lib.bd_dropout_f32(_lib.ptr(dx), _lib.ptr(dx), M, d, _dp(drop), 0, _s()), "bd_dropout_f32")

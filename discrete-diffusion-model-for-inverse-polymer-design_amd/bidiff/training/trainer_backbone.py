@@ -4,8 +4,10 @@ Drop-in for ``src/training/trainer_backbone.py`` (``BackboneTrainer``, :61-715):
 constructor, ``train()`` / ``load_checkpoint()``, history dict, checkpoint dict layout
 (``epoch, global_step, model_state_dict, optimizer_state_dict, scheduler_state_dict, val_loss,
 best_val_loss, config``) and CSV files. Differences that follow from the native step:
-  * the denoiser always computes in bf16 on the MFMA path. ``use_amp`` keeps what ``GradScaler`` contributes to
-    the reference's step (trainer_backbone.py:129,439-453): a step whose gradients hold an inf or NaN is skipped
+  * the denoiser computes in bf16 on the MFMA path, which is the reference's step under ``use_amp: true`` (its
+    configs' setting); ``use_amp: false`` (fp32 products, trainer_backbone.py:434) is refused with
+    NotImplementedError rather than trained in narrower arithmetic. ``use_amp`` also keeps what ``GradScaler``
+    contributes to the reference's step (trainer_backbone.py:129,439-453): a step whose gradients hold an inf or NaN is skipped
     and does not count for the bias corrections (``optimizer.skip_nonfinite``; decided on the device, without the
     host synchronisation ``scaler.step`` makes). The scale factor itself is dropped: multiplying the loss by a power
     of two and dividing the gradients by it again is exact in fp32;
@@ -60,6 +62,15 @@ class BackboneTrainer:
 
         opt = config.get("optimization", {})
         self.use_amp = bool(opt.get("use_amp", False))
+        if not self.use_amp:
+            # the reference runs the step under autocast(enabled=use_amp) (trainer_backbone.py:434): without it every
+            # product of the forward and backward pass is fp32. The training kernels here compute in bf16 (fp32
+            # accumulation, fp32 master weights and optimizer); fp32 exists for inference only
+            # (DiffusionBackbone.compute_dtype = "fp32"). Training in narrower arithmetic than asked for is refused.
+            raise NotImplementedError(
+                "BackboneTrainer: optimization.use_amp = false (or absent) asks for an fp32 training step; the bidiff "
+                "training kernels compute in bf16 only. Set optimization.use_amp: true (what the reference's "
+                "configs/config.yaml does) to train with bf16 products and fp32 accumulation.")
         self.grad_accum_steps = int(opt.get("gradient_accumulation_steps", 1))
         tc = config["training_backbone"]
         self.learning_rate = _f(tc["learning_rate"], "learning_rate")
@@ -99,7 +110,7 @@ class BackboneTrainer:
             if off is None or os.environ.get("BD_OVERLAP_ALLREDUCE", "1") == "0":
                 off = self.optimizer.flat_grad.numel()           # nothing to start early
             self._exchange = GradientExchange(self.optimizer.flat_grad, off, self.world_size)
-            _autograd.set_tail_ready_hook(self._exchange.tail_ready, split_layer)
+            _autograd.set_tail_ready_hook(self._exchange.tail_ready, split_layer, model=bb)
         self.global_step = 0
         self.best_val_loss = float("inf")
         self.train_losses, self.val_losses, self.val_steps, self.learning_rates = [], [], [], []
@@ -147,7 +158,8 @@ class BackboneTrainer:
     def _train_step(self, batch, should_step: bool) -> float:
         ids = batch["input_ids"].to(self.device)
         am = batch["attention_mask"].to(self.device)
-        return float(self.train_step_device(ids, am, should_step, lengths=batch.get("lengths")).item())
+        from ..data.loader import ROW_LENGTHS_KEY
+        return float(self.train_step_device(ids, am, should_step, lengths=batch.get(ROW_LENGTHS_KEY)).item())
 
     def _validate(self) -> float:
         self.model.eval()
@@ -254,7 +266,7 @@ class BackboneTrainer:
                   for i, (a, b) in enumerate(zip(self.epoch_train_losses, self.epoch_val_losses))])
 
     def load_checkpoint(self, checkpoint_path: str):
-        ck = torch.load(checkpoint_path, map_location=self.device, weights_only=False)  # file written by this class
+        ck = torch.load(checkpoint_path, map_location=self.device, weights_only=True)   # tensors, numbers, the config dict
         self.model.load_state_dict(ck["model_state_dict"])
         self.optimizer.load_state_dict(ck["optimizer_state_dict"])
         self.scheduler.load_state_dict(ck["scheduler_state_dict"])

@@ -49,11 +49,29 @@ struct MegaArgs {
   // layer's attention phase and leaves the residual rows of the chosen positions in xsel[seq * row_cap + i, :]; the
   // tail kernel runs the last feed-forward block and the final LayerNorm on those rows.
   const int* row_pos;
-  const unsigned char* need_all;
+  unsigned char* need_all;
   float* xsel;
   int row_cap;
   MegaLayer layers[MEGA_MAX_LAYERS];
 };
+
+// Clock diagnostics (bd_clock_stamps_set): while a buffer is set, workgroup b < cap leaves s_memtime / s_memrealtime at
+// its start in buf[4 b], [4 b + 1] and at its end in [4 b + 2], [4 b + 3]. The buffer lives in a device variable that
+// is read where a stamp is taken (not a kernel argument: nothing of it stays in registers across the kernel).
+struct ClockStamps { unsigned long long* buf; int cap; };
+__device__ ClockStamps g_clock_stamps = {nullptr, 0};
+
+__device__ __forceinline__ void clock_stamp(int which) {
+#ifdef BD_AB_NO_CLOCK_STAMPS      // comparison builds only (tools_prof/ab_mega.py)
+  return;
+#endif
+  if (threadIdx.x != 0) return;
+  const volatile ClockStamps* cs = &g_clock_stamps;
+  unsigned long long* buf = cs->buf;
+  if (buf == nullptr || (int)blockIdx.x >= cs->cap) return;
+  buf[4 * (size_t)blockIdx.x + which] = __builtin_amdgcn_s_memtime();
+  buf[4 * (size_t)blockIdx.x + which + 1] = __builtin_amdgcn_s_memrealtime();
+}
 
 // Final LayerNorm (affine) of the wave's 32 rows in accumulator layout -> the lane's half of its bf16 hidden row
 // (orow = start of the row, null: nothing stored).
@@ -129,6 +147,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int tokc = valid ? tok : L - 1;                 // lanes past the sequence shadow its last row
   const size_t row = (size_t)seq * L + tokc;
   stagger_start(p.stagger_blocks, p.stagger_units);
+  clock_stamp(0);
 
   // ---- embeddings: x = (token + position) + timestep, straight into accumulator layout
   f32x16 acc[NT32];
@@ -213,15 +232,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __builtin_amdgcn_s_barrier();
     if (p.tables_by_dma && !stop_here) fetch_ffn_tables(lw);   // nobody reads the feed-forward tables before the next barrier
     attn_phase<NT, DH, H>(ap, smem, acc);
-    if (p.row_pos != nullptr && l + 1 == p.n_layers && valid) {
-      // the residual rows of the chosen positions, as they stand behind the last attention block, for the tail kernel
-      // (also from a workgroup that goes on because another of its sequences needs every row: the tail kernel
-      // finishes the listed rows of every sequence that is not flagged itself, with the same bits)
-      int slot = -1;
-      for (int i = 0; i < p.row_cap; ++i)
-        if (p.row_pos[(size_t)seq * p.row_cap + i] == tok) slot = seq * p.row_cap + i;
-      if (slot >= 0) store_rows(acc, p.xsel + (size_t)slot * D + 4 * h);
-    }
     if (stop_here) break;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -230,10 +240,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     ffn_phase<NT>(fp, smem, acc);
   }
 
-  if (rows_only) return;
+  if (rows_only) {
+    // the residual rows of the chosen positions, as they stand behind the last attention block, for the tail kernel
+    if (valid) {
+      int slot = -1;
+      for (int i = 0; i < p.row_cap; ++i)
+        if (p.row_pos[(size_t)seq * p.row_cap + i] == tok) slot = seq * p.row_cap + i;
+      if (slot >= 0) store_rows(acc, p.xsel + (size_t)slot * D + 4 * h);
+    }
+    clock_stamp(2);
+    return;
+  }
+  if (p.row_pos != nullptr && threadIdx.x < 4) {
+    // this workgroup finishes every row of all its sequences because one of them needs that: the others are marked
+    // (2), so that the tail kernel leaves their listed rows alone
+    const int w = threadIdx.x;
+    int sw = p.wave_seq ? p.wave_seq[4 * (size_t)blockIdx.x + w] : (int)blockIdx.x * NSEG + (w >> (SW >> 1));
+    if (sw >= 0 && sw < p.B && p.need_all[sw] == 0) p.need_all[sw] = 2;
+  }
 
   // ---- final LayerNorm (affine) -> bf16 hidden rows
   final_norm_store<NT>(acc, p.lnf_g, p.lnf_b, p.eps, valid ? p.hidden + row * D : nullptr, h);
+  clock_stamp(2);
 }
 
 // The last feed-forward block and the final LayerNorm for the chosen rows that backbone_mega_kernel left in xsel
@@ -242,7 +270,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 struct TailArgs {
   const float* xsel;             // [n_slots, d] residual rows behind the last attention block
   const int* row_pos;            // [n_slots] position inside sequence slot / row_cap, -1: empty slot
-  const unsigned char* need_all; // [B] sequences whose rows the main kernel finished itself
+  const unsigned char* need_all; // [B] non-zero: sequences whose rows the main kernel finished itself
   unsigned short* hidden;        // [B * L, d]
   const float* lnf_g;
   const float* lnf_b;
@@ -341,7 +369,7 @@ bool mega_tables_by_dma(const bd_backbone_desc& c) {
 // Chosen rows of a launch (all null / 0: every row is computed)
 struct RowChoice {
   const int* row_pos;
-  const unsigned char* need_all;
+  unsigned char* need_all;
   float* xsel;
   int row_cap;
 };
@@ -447,7 +475,7 @@ extern "C" int bd_backbone_forward_rows_supported(const bd_backbone_desc* c, int
 
 extern "C" int bd_backbone_forward_rows(const bd_backbone_desc* desc, const long long* ids, const long long* timesteps,
                                         const unsigned char* keymask, const int* wave_seq, int n_blocks, int B, int L,
-                                        const int* row_pos, const unsigned char* need_all, int row_cap,
+                                        const int* row_pos, unsigned char* need_all, int row_cap,
                                         void* workspace, long long workspace_bytes, void* hidden_out, void* stream) {
   BD_REQUIRE(desc && row_pos && need_all && workspace && hidden_out, "bd_backbone_forward_rows: null operand");
   BD_REQUIRE(B > 0 && L > 0, "bd_backbone_forward_rows: empty batch");
@@ -463,4 +491,12 @@ extern "C" int bd_backbone_forward_rows(const bd_backbone_desc* desc, const long
   BD_REQUIRE(bd_backbone_forward_rows_supported(desc, L), "bd_backbone_forward_rows: unsupported model shape or L=%d", L);
   return mega_impl(desc, ids, timesteps, keymask, wave_seq, n_blocks, B, L, nullptr, hidden_out, stream,
                    RowChoice{row_pos, need_all, (float*)workspace, row_cap});
+}
+
+extern "C" int bd_clock_stamps_set(unsigned long long* stamps, int n_workgroups) {
+  BD_REQUIRE(stamps == nullptr || n_workgroups > 0, "bd_clock_stamps_set: a buffer needs a positive workgroup count");
+  const ClockStamps cs{stamps, stamps ? n_workgroups : 0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_clock_stamps), &cs, sizeof(cs)) != hipSuccess)
+    return bd_fail(BD_ERR_LAUNCH, "bd_clock_stamps_set: writing the device variable failed");
+  return BD_OK;
 }

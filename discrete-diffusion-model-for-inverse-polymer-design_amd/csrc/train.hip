@@ -1542,7 +1542,35 @@ constexpr int BD_STATIC_MAX_DEVICES = 64;
 static float* g_static_delta_ptr[BD_STATIC_MAX_DEVICES] = {};
 static std::mutex g_static_delta_mu;
 
-extern "C" long long bd_attention_bwd_static_capacity(void) { return BD_STATIC_DELTA_FLOATS; }
+// The scratch array's address on the current device: looked up once per device (under the mutex), afterwards one
+// atomic load. Null on failure (bd_last_error says why).
+static float* static_delta_of_current_device(const char* who) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= BD_STATIC_MAX_DEVICES) {
+    bd_fail(BD_ERR_ARG, "%s: no current device (or device index >= %d)", who, BD_STATIC_MAX_DEVICES);
+    return nullptr;
+  }
+  float* delta = __atomic_load_n(&g_static_delta_ptr[dev], __ATOMIC_ACQUIRE);
+  if (delta != nullptr) return delta;
+  std::lock_guard<std::mutex> lk(g_static_delta_mu);
+  if (g_static_delta_ptr[dev] == nullptr) {
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(bd_static_delta));
+    if (e != hipSuccess || p == nullptr) {
+      bd_fail(BD_ERR_LAUNCH, "%s: hipGetSymbolAddress failed: %s", who, hipGetErrorString(e));
+      return nullptr;
+    }
+    __atomic_store_n(&g_static_delta_ptr[dev], (float*)p, __ATOMIC_RELEASE);
+  }
+  return g_static_delta_ptr[dev];
+}
+
+// Also the set-up call: it resolves the scratch address for the current device, so that a later
+// bd_attention_bwd_static on that device (under stream capture, say) makes no runtime lookup.
+extern "C" long long bd_attention_bwd_static_capacity(void) {
+  (void)static_delta_of_current_device("bd_attention_bwd_static_capacity");
+  return BD_STATIC_DELTA_FLOATS;
+}
 
 extern "C" int bd_attention_bwd_static(const void* qkv, const unsigned char* keymask, const void* out, const void* dout,
                                        const float* lse, void* dqkv, int B, int L, int H, int head_dim, void* stream) {
@@ -1550,21 +1578,8 @@ extern "C" int bd_attention_bwd_static(const void* qkv, const unsigned char* key
   BD_REQUIRE((long long)B * H * L <= BD_STATIC_DELTA_FLOATS,
              "bd_attention_bwd_static: B*H*L = %lld exceeds the built-in scratch of %lld entries (use bd_attention_bwd "
              "with a caller buffer)", (long long)B * H * L, BD_STATIC_DELTA_FLOATS);
-  int dev = -1;
-  BD_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < BD_STATIC_MAX_DEVICES,
-             "bd_attention_bwd_static: no current device (or device index >= %d)", BD_STATIC_MAX_DEVICES);
-  float* delta = nullptr;
-  {
-    std::lock_guard<std::mutex> lk(g_static_delta_mu);
-    if (g_static_delta_ptr[dev] == nullptr) {
-      void* p = nullptr;
-      const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(bd_static_delta));
-      if (e != hipSuccess || p == nullptr)
-        return bd_fail(BD_ERR_LAUNCH, "bd_attention_bwd_static: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
-      g_static_delta_ptr[dev] = (float*)p;
-    }
-    delta = g_static_delta_ptr[dev];
-  }
+  float* const delta = static_delta_of_current_device("bd_attention_bwd_static");
+  if (delta == nullptr) return BD_ERR_LAUNCH;
   // every entry a kernel reads (queries 0..L-1 of each head) is written by the dq kernel of this call first:
   // nothing of an earlier call's contents is consumed, so nothing has to be cleared
   return bd_attention_bwd_drop(qkv, keymask, out, dout, lse, delta, dqkv, B, L, H, head_dim, nullptr, 0u, stream);

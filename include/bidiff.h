@@ -93,7 +93,11 @@ int bd_gemm_panel(const void* A, const void* W, const float* bias, void* out, co
  * normalise = LayerNorm without affine; the caller folds gamma into W1 (W1' = W1 * gamma) and beta
  * into b1 (b1' = b1 + W1 * beta). The [M, F] hidden activations are never written to memory.
  * The GELU runs in packed f16 and feeds the second product on the f16 matrix instruction (W2 is stored as f16 in
- * the stream; every bf16 weight of normal f16 magnitude converts exactly).
+ * the stream; every bf16 weight of normal f16 magnitude converts exactly). Limits that follow, which the CALLER
+ * checks before it packs (DiffusionBackbone.packed does; layers outside them run bd_gemm_bf16 with the GELU
+ * epilogue instead): first-product outputs W1' * normalise(x) + b1' inside +-65504 (beyond that the conversion
+ * saturates: the block returns the result for an activation of +-65504); W2 entries below 2^-14 in magnitude lose
+ * bits (absolute error at most 2^-25 each, or the entry itself where the matrix instruction drops f16 subnormals).
  * wpack is the weight stream made by bd_ffn_pack_weights from W1' (bf16 [F, d]) and W2 (bf16 [d, F]);
  * it holds bd_ffn_pack_bytes(d, F) bytes. Supported: d in {128, 256, 384}, F % 32 == 0, F <= 4096.
  * Replaces TransformerBlock.forward's  x + ffn(ln2(x))  (src/model/backbone.py:128, FeedForward :85-96). */
@@ -227,18 +231,19 @@ int bd_backbone_forward_ragged(const bd_backbone_desc* desc, const long long* id
 
 /* The forward for a reverse step that reads few hidden rows: hidden_out [B*L, d] bf16 receives the final-norm rows
  * of the positions row_pos[b * row_cap + i] (>= 0) of every sequence b, and all rows of the sequences with
- * need_all[b] != 0 (bd_sample_choose_rows writes both); any other row of hidden_out either keeps what it held
- * or receives its final-norm row too (the rows of a sequence that shares a workgroup with a flagged one). The
- * rows written carry the bits bd_backbone_mega writes. Every layer runs for every row except the last
- * feed-forward block and the final LayerNorm, which only the listed rows need (the last layer's keys and
- * values need every row of the layers below).
+ * need_all[b] != 0 (bd_sample_choose_rows writes both lists); any other row of hidden_out either keeps what it
+ * held or receives its final-norm row too. The rows written carry the bits bd_backbone_mega writes. Every layer runs
+ * for every row except the last feed-forward block and the final LayerNorm, which only the listed rows need (the
+ * last layer's keys and values need every row of the layers below).
+ * need_all is in / out: a sequence that shares a workgroup with a flagged one has all its rows finished as well and
+ * is marked with 2 (bd_sample_choose_rows rewrites the list for the next step).
  * wave_seq / n_blocks: as for bd_backbone_mega_ragged, or null / 0. workspace: B * row_cap * d floats.
  * Serves the reverse loop at t > 1 (src/sampling/sampler.py:661-718: the step reads the logits of the positions
  * it draws, :686-693; their choice does not depend on the logits, :676-686). */
 int bd_backbone_forward_rows_supported(const bd_backbone_desc* desc, int L);
 int bd_backbone_forward_rows(const bd_backbone_desc* desc, const long long* ids, const long long* timesteps,
                              const unsigned char* keymask, const int* wave_seq, int n_blocks, int B, int L,
-                             const int* row_pos, const unsigned char* need_all, int row_cap,
+                             const int* row_pos, unsigned char* need_all, int row_cap,
                              void* workspace, long long workspace_bytes, void* hidden_out, void* stream);
 
 /* Embeddings + the first n_run blocks only; resid_out [B*L, d] fp32 receives the residual stream
@@ -407,7 +412,10 @@ int bd_attention_bwd(const void* qkv, const unsigned char* keymask, const void* 
  * [B, H, L] fp32 row sums live in a file-scope device array of bd_attention_bwd_static_capacity() = 2^22 entries
  * (16 MiB, held per GPU until the process ends); a larger B*H*L is rejected with BD_ERR_ARG. The call allocates
  * nothing (with the event profiler off). Calls that overlap on one GPU - other streams or threads - share that
- * array and race; calls on one stream, one after another, are safe. */
+ * array and race; calls on one stream, one after another, are safe.
+ * bd_attention_bwd_static_capacity() is also the set-up call: it looks the array's address up for the CURRENT
+ * device (once per device). Call it on every device before the first bd_attention_bwd_static there that runs under
+ * stream capture; without it that first call makes the lookup itself (a runtime query, not a stream operation). */
 long long bd_attention_bwd_static_capacity(void);
 int bd_attention_bwd_static(const void* qkv, const unsigned char* keymask, const void* out, const void* dout,
                             const float* lse, void* dqkv, int B, int L, int H, int head_dim, void* stream);
@@ -680,6 +688,14 @@ int bd_prof_read(long long* launches, double* total_ms, double* total_flops, int
  * 9 masked cross-entropy, 10 embedding / corruption / dropout / casts, 11 optimizer, 12 reverse step and
  * repairs; -1 = all families together. */
 int bd_prof_read_kind(int kind, long long* launches, double* total_ms, double* total_flops, int reset);
+
+/* Clock diagnostics of the single-launch forward (bd_backbone_mega and the entry points that use it): while a
+ * buffer is set, workgroup b < n_workgroups of every such launch writes four 64-bit words to stamps[4 b ..]:
+ * the shader-clock counter and the 100 MHz real-time counter when it starts, and both again when it ends. The
+ * sustained clock of a launch is (end - start) of the first counter over (end - start) of the second, times
+ * 100 MHz, e.g. as the median over workgroups: it tells a box that holds a lower clock under this load from a
+ * slower kernel. stamps = null (the initial state) turns the stamps off; process-wide, not thread-safe. */
+int bd_clock_stamps_set(unsigned long long* stamps, int n_workgroups);
 
 #ifdef __cplusplus
 }

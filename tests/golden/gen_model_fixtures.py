@@ -29,6 +29,36 @@ def sha(t):
     return hashlib.sha256(t.detach().contiguous().numpy().tobytes()).hexdigest()
 
 
+def small_architecture():
+    """The benchmark architecture itself (d 384, 6 layers, 3 heads of 128, ffn 1536, L = 128) at V = 39 (SMILES) and
+    V = 803 (SMILES_BPE): logits, and the training forward's dict (timesteps, noisy ids, indicator, loss, logits)
+    with the reference's own RNG order. Written to model_small.npz (V = 803 logits at every fourth position)."""
+    out = {}
+    for V_ in (39, 803):
+        cfg, ids, attn, t, stride = RI.small_arch_case(V_)
+        torch.manual_seed(42)
+        bb = DiffusionBackbone(**cfg).eval()
+        RI.perturb_state_dict(bb.state_dict(), 5)
+        with torch.no_grad():
+            lg = bb(torch.from_numpy(ids), torch.from_numpy(t), torch.from_numpy(attn)).numpy()
+        out[f"v{V_}/ids"], out[f"v{V_}/attn"], out[f"v{V_}/t"] = ids, attn, t
+        out[f"v{V_}/logits"] = lg[:, ::stride].copy()
+        dm = DiscreteMaskingDiffusion(bb, num_steps=100, mask_token_id=1, pad_token_id=0, bos_token_id=2, eos_token_id=3)
+        ids2 = ids.copy()
+        ids2[0, 3:9] = np.arange(6, 12)  # no MASK in the clean input
+        torch.manual_seed(78)
+        with torch.no_grad():
+            res = dm(torch.from_numpy(ids2), torch.from_numpy(attn))
+        out[f"v{V_}/fwd_ids"] = ids2
+        out[f"v{V_}/fwd_timesteps"] = res["timesteps"].numpy()
+        out[f"v{V_}/fwd_noisy_ids"] = res["noisy_ids"].numpy()
+        out[f"v{V_}/fwd_mask_indicator"] = res["mask_indicator"].numpy()
+        out[f"v{V_}/fwd_loss"] = np.array(res["loss"].item(), dtype=np.float32)
+        out[f"v{V_}/fwd_logits"] = res["logits"].numpy()[:, ::stride].copy()
+    np.savez_compressed(os.path.join(HERE, "model_small.npz"), **out)
+    print("wrote model_small.npz", os.path.getsize(os.path.join(HERE, "model_small.npz")), "bytes")
+
+
 def main():
     torch.set_num_threads(4)
     blob = {}
@@ -130,6 +160,7 @@ def main():
     blob["fwd/loss"] = np.array(out["loss"].item(), dtype=np.float32)
     blob["fwd/logits"] = out["logits"].detach().numpy()
 
+    small_architecture()
     np.savez_compressed(os.path.join(HERE, "model.npz"), **blob)
     with open(os.path.join(HERE, "model_meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)

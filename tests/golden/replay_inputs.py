@@ -191,6 +191,17 @@ SMALL_CFG = dict(vocab_size=39, hidden_size=384, num_layers=6, num_heads=3, ffn_
                  max_position_embeddings=256, num_diffusion_steps=100, dropout=0.1, pad_token_id=0)
 
 
+def small_arch_case(V):
+    """Config and inputs of the benchmark-architecture golden (model_small.npz): two rows of 128 tokens, the second
+    cut to 90; weights = seeded init (torch.manual_seed(42)) + perturb_state_dict(., 5)."""
+    cfg = dict(SMALL_CFG, vocab_size=V, dropout=0.0)
+    ids, attn, t = (x[[0, 5]].copy() for x in backbone_inputs(cfg, 61, B=6, L=128))
+    attn[1, 90:] = 0
+    ids[1, 90:] = 0
+    ids[1, 89] = 3
+    return cfg, ids, attn, t, (1 if V == 39 else 4)
+
+
 PROPERTY_HIDDEN = [256, 64]      # the reference default of PropertyHead (property_head.py:17)
 
 

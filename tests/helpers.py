@@ -186,3 +186,13 @@ def hip_fixup(tb, dt, ids, logits, do_fix=True, natural_eos=False, attn=None, ke
     f.natural_eos = int(natural_eos)
     _lib.check(_lib.lib().bd_sample_fixup(C.byref(f), _lib.stream_handle()), "bd_sample_fixup")
     torch.cuda.synchronize()
+
+
+def logits_errors(got, ref, floor_frac=0.25):
+    """(max-norm relative error max|got - ref| / max|ref|, largest per-element relative error over the entries with
+    |ref| >= floor_frac * max|ref|). A max-norm bound e bounds the second figure by e / floor_frac and says nothing
+    about entries below the floor."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    scale = np.abs(ref).max()
+    big = np.abs(ref) >= floor_frac * scale
+    return float(np.abs(got - ref).max() / scale), float((np.abs(got - ref)[big] / np.abs(ref)[big]).max())

@@ -49,6 +49,26 @@ def test_fp32_logits_match_reference_golden(gpu_device, name):
     assert rel_err(pooled, BLOB[f"{name}/pooled_mean"]) < FP32_TOL
 
 
+@pytest.mark.parametrize("V", [39, 803])
+def test_fp32_benchmark_architecture_matches_reference_golden(gpu_device, V, capsys):
+    """The benchmark architecture (d 384, 6 layers, 3 heads of 128, L = 128) in fp32 mode against the reference's own
+    logits at that size: 1e-5 of the largest logit; per-element relative error above a quarter of the largest 4e-5."""
+    blob = np.load(os.path.join(H.GOLDEN, "model_small.npz"))
+    cfg, ids, attn, t, stride = RI.small_arch_case(V)
+    torch.manual_seed(42)
+    bb = DiffusionBackbone(**cfg).eval()
+    RI.perturb_state_dict(bb.state_dict(), 5)
+    bb = bb.to(gpu_device)
+    bb.compute_dtype = "fp32"
+    with torch.no_grad():
+        got = bb(torch.from_numpy(ids).to(gpu_device), torch.from_numpy(t).to(gpu_device),
+                 torch.from_numpy(attn).to(gpu_device)).cpu().numpy()[:, ::stride]
+    e_max, e_rel = H.logits_errors(got, blob[f"v{V}/logits"])
+    with capsys.disabled():
+        print(f"\n[V={V} fp32] logits max-norm error {e_max:.2e}, per-element relative error (|ref| >= max/4) {e_rel:.2e}")
+    assert e_max < FP32_TOL and e_rel < 4 * FP32_TOL
+
+
 @pytest.mark.parametrize("hidden,heads,layers,ffn,B,L", [
     (384, 3, 6, 1536, 6, 128),     # the benchmark architecture
     (384, 6, 2, 1536, 3, 100),     # heads of 64, ragged tile edges (M = 300)

@@ -71,6 +71,44 @@ def test_small_config_logits_match_oracle(gpu_device):
         assert rel_err(got, ref) < BF16_TOL
 
 
+@pytest.mark.parametrize("V", [39, 803])
+def test_benchmark_architecture_matches_reference_golden(gpu_device, V, capsys):
+    """d 384, 6 layers, 3 heads of 128, L = 128 at V = 39 / 803 against vectors the reference produced at that size
+    (model_small.npz): logits in bf16 within 2e-2 of the largest logit, per-element relative error of the logits
+    above a quarter of the largest within 8e-2 (what the max-norm bound implies there; reported, smaller in
+    practice); the training forward's corruption bit for bit and its loss."""
+    blob = np.load(os.path.join(H.GOLDEN, "model_small.npz"))
+    cfg, ids, attn, t, stride = RI.small_arch_case(V)
+    torch.manual_seed(42)
+    bb = DiffusionBackbone(**cfg).eval()
+    RI.perturb_state_dict(bb.state_dict(), 5)
+    dm = DiscreteMaskingDiffusion(bb, num_steps=100, mask_token_id=1, pad_token_id=0, bos_token_id=2,
+                                  eos_token_id=3).to(gpu_device).eval()
+    dev = gpu_device
+    with torch.no_grad():
+        got = dm.backbone(torch.from_numpy(ids).to(dev), torch.from_numpy(t).to(dev), torch.from_numpy(attn).to(dev))
+    got = got.float().cpu().numpy()[:, ::stride]
+    e_max, e_rel = H.logits_errors(got, blob[f"v{V}/logits"])
+    with capsys.disabled():
+        print(f"\n[V={V} bf16] logits max-norm error {e_max:.2e}, per-element relative error (|ref| >= max/4) {e_rel:.2e}")
+    assert e_max < BF16_TOL and e_rel < 4 * BF16_TOL
+    # the training forward with the reference's draws
+    ids2 = blob[f"v{V}/fwd_ids"]
+    torch.manual_seed(78)
+    tt = torch.randint(1, 101, (2,))
+    u = torch.rand(2, 128)
+    with torch.no_grad():
+        noisy, ind = dm.forward_process(torch.from_numpy(ids2).to(dev), tt.to(dev), torch.from_numpy(attn).to(dev),
+                                        uniforms=u.to(dev))
+        lg = dm.backbone(noisy, tt.to(dev), torch.from_numpy(attn).to(dev))
+        loss = dm._compute_loss(lg, torch.from_numpy(ids2).to(dev), ind, torch.from_numpy(attn).to(dev))
+    np.testing.assert_array_equal(noisy.cpu().numpy(), blob[f"v{V}/fwd_noisy_ids"])
+    np.testing.assert_array_equal(ind.cpu().numpy(), blob[f"v{V}/fwd_mask_indicator"])
+    e_max, e_rel = H.logits_errors(lg.float().cpu().numpy()[:, ::stride], blob[f"v{V}/fwd_logits"])
+    assert e_max < BF16_TOL and e_rel < 4 * BF16_TOL
+    assert abs(float(loss.item()) - float(blob[f"v{V}/fwd_loss"])) < BF16_TOL * float(blob[f"v{V}/fwd_loss"])
+
+
 @pytest.mark.parametrize("hidden,heads,layers,ffn,B,L", [
     (384, 8, 2, 1536, 4, 96),      # the reference's default model block: 8 heads of 48 (padded to 64 inside)
     (256, 4, 2, 1024, 3, 128),     # the reference's "tiny" size: fused kernels with head_dim 64
@@ -368,3 +406,35 @@ def test_block_level_modules_are_callable_and_match_the_fp32_restatement(gpu_dev
     with pytest.raises(RuntimeError, match="ROCm device"):
         with torch.no_grad():
             blk(x, mask)
+
+
+@pytest.mark.parametrize("case", ["fc1_beyond_f16", "fc2_below_f16_normal", "in_range"])
+def test_feed_forward_weights_outside_f16_keep_the_bf16_kernels(gpu_device, case):
+    """The fused feed-forward phase works in f16 behind the first product. Weights it cannot serve (first-product
+    outputs that may pass +-65504; second-layer weights below the smallest normal f16) are recognised when the
+    weights are packed, that model runs the bf16 kernels, and the logits stay within the bf16 bound of the oracle."""
+    from bidiff import _lib
+    import ctypes as C
+    cfg = dict(RI.SMALL_CFG, num_layers=2, dropout=0.0)
+    torch.manual_seed(4)
+    bb = DiffusionBackbone(**cfg).eval()
+    RI.perturb_state_dict(bb.state_dict(), 6)
+    with torch.no_grad():
+        if case == "fc1_beyond_f16":
+            bb.layers[1].ffn.fc1.weight.mul_(30000.0)      # pre-activations up to about 1e5
+            bb.layers[1].ffn.fc2.weight.mul_(1.0 / 30000.0)
+        elif case == "fc2_below_f16_normal":
+            bb.layers[0].ffn.fc2.weight.mul_(2e-4)         # every entry below 6.1e-5
+    sd = {k: v.clone() for k, v in bb.state_dict().items()}
+    ids, attn, t = RI.backbone_inputs(cfg, 12, B=6, L=128)
+    with torch.no_grad():
+        ref = BR.logits(sd, cfg, torch.from_numpy(ids), torch.from_numpy(t), torch.from_numpy(attn)).numpy()
+        bbg = bb.to(gpu_device)
+        got = bbg(torch.from_numpy(ids).to(gpu_device), torch.from_numpy(t).to(gpu_device),
+                  torch.from_numpy(attn).to(gpu_device)).cpu().numpy()
+    pk = bbg.packed()
+    fused = [bool(pk.layers[i].ffn_pack) for i in range(2)]
+    assert fused == {"fc1_beyond_f16": [True, False], "fc2_below_f16_normal": [False, True], "in_range": [True, True]}[case]
+    assert _lib.lib().bd_backbone_mega_supported(C.byref(pk.desc), 128) == int(case == "in_range")
+    assert np.isfinite(got).all()
+    assert rel_err(got, ref) < BF16_TOL

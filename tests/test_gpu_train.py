@@ -591,6 +591,19 @@ def test_training_steps_follow_fp32_reference_trajectory(gpu_device):
         assert (p.detach().cpu() - ref_params[k].detach()).abs().max().item() < 5e-3, k
 
 
+def test_trainer_refuses_fp32_training(gpu_device, tmp_path):
+    """use_amp false means an fp32 step in the reference (autocast(enabled=use_amp), trainer_backbone.py:434); the
+    training kernels compute in bf16, so the trainer says so instead of training in narrower arithmetic."""
+    from bidiff.training import BackboneTrainer
+    cfg, model, sd, ids, attn, t = _grad_setup("tiny_h2", gpu_device, B=4, L=24)
+    tc = {"learning_rate": 1e-3, "weight_decay": 0.01, "warmup_steps": 1, "max_steps": 2, "gradient_clip_norm": 1.0,
+          "eval_every": 10, "save_every": 10}
+    for opt in ({"use_amp": False}, {}):
+        with pytest.raises(NotImplementedError, match="use_amp"):
+            BackboneTrainer(model, [], [], {"optimization": opt, "training_backbone": tc}, device=str(gpu_device),
+                            output_dir=str(tmp_path))
+
+
 def test_trainer_runs_and_checkpoints(gpu_device, tmp_path):
     from bidiff.training import BackboneTrainer
     cfg, model, sd, ids, attn, t = _grad_setup("tiny_h2", gpu_device, B=8, L=24)
@@ -603,7 +616,7 @@ def test_trainer_runs_and_checkpoints(gpu_device, tmp_path):
     hist = tr.train()
     assert len(hist["train_losses"]) == 12 and all(math.isfinite(x) for x in hist["train_losses"])
     assert hist["train_losses"][-1] < hist["train_losses"][0]
-    ck = torch.load(tmp_path / "checkpoints" / "backbone_best.pt", map_location="cpu", weights_only=False)
+    ck = torch.load(tmp_path / "checkpoints" / "backbone_best.pt", map_location="cpu", weights_only=True)
     assert set(ck) == {"epoch", "global_step", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict",
                        "val_loss", "best_val_loss", "config"}
     assert list(ck["model_state_dict"].keys()) == list(sd.keys())

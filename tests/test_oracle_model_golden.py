@@ -148,3 +148,36 @@ def test_forward_result_dict_builds_deferred_entries_on_first_access():
         out3["missing"]
     assert _Outputs({"loss": 1.0}, {"logits": build}) == {"loss": 1.0, "logits": "L"}
     assert dict(_Outputs({"loss": 1.0}, {"logits": build})) == {"loss": 1.0, "logits": "L"}
+
+
+@pytest.mark.parametrize("V", [39, 803])
+def test_oracle_at_the_benchmark_architecture(V):
+    """d 384, 6 layers, 3 heads of 128, L = 128 (SMILES V = 39, SMILES_BPE V = 803): the restatement's logits and its
+    replay of the training forward against vectors from the reference at that very size (model_small.npz)."""
+    blob = np.load(os.path.join(H.GOLDEN, "model_small.npz"))
+    cfg, ids, attn, t, stride = RI.small_arch_case(V)
+    torch.manual_seed(42)
+    bb = DiffusionBackbone(**cfg).eval()
+    RI.perturb_state_dict(bb.state_dict(), 5)
+    sd = bb.state_dict()
+    for k, a in (("ids", ids), ("attn", attn), ("t", t)):
+        np.testing.assert_array_equal(a, blob[f"v{V}/{k}"])
+    want = blob[f"v{V}/logits"]
+    with torch.no_grad():
+        lg = BR.logits(sd, cfg, torch.from_numpy(ids), torch.from_numpy(t), torch.from_numpy(attn)).numpy()[:, ::stride]
+    assert np.abs(lg - want).max() / np.abs(want).max() < 1e-5
+    # training forward: t = randint first, then the corruption uniforms
+    ids2 = blob[f"v{V}/fwd_ids"]
+    torch.manual_seed(78)
+    tt = torch.randint(1, 101, (2,))
+    u = torch.rand(2, 128)
+    np.testing.assert_array_equal(tt.numpy(), blob[f"v{V}/fwd_timesteps"])
+    noisy, ind = ora.corrupt(ids2, attn, tt.numpy(), BR.mask_schedule(100).numpy(), u.numpy(), 1, 0, 2, 3)
+    np.testing.assert_array_equal(noisy, blob[f"v{V}/fwd_noisy_ids"])
+    np.testing.assert_array_equal(ind, blob[f"v{V}/fwd_mask_indicator"])
+    with torch.no_grad():
+        lg = BR.logits(sd, cfg, torch.from_numpy(noisy), tt, torch.from_numpy(attn))
+        loss = BR.masked_ce(lg, torch.from_numpy(ids2), torch.from_numpy(ind), torch.from_numpy(attn))
+    want = blob[f"v{V}/fwd_logits"]
+    assert np.abs(lg.numpy()[:, ::stride] - want).max() / np.abs(want).max() < 1e-5
+    assert abs(loss.item() - float(blob[f"v{V}/fwd_loss"])) < 1e-5

@@ -4,6 +4,9 @@ sys.path.insert(0, 'discrete-diffusion-model-for-inverse-polymer-design_amd'); s
 from bidiff import _lib
 if len(sys.argv) > 1 and sys.argv[1] != "base":
     _lib.LIB_PATH = sys.argv[1]
+    import ctypes
+    _h = ctypes.CDLL(sys.argv[1])          # an older build lacks the newer entry points: bind what it has
+    _lib.SIGNATURES = {k: v for k, v in _lib.SIGNATURES.items() if hasattr(_h, k)}
 from bidiff.model.backbone import DiffusionBackbone
 dev = torch.device('cuda:0')
 torch.manual_seed(42)
