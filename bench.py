@@ -609,7 +609,7 @@ def main():
         # so the figure comes from the committed rocprofv3 --pmc passes (profiles/*_pmc_traffic.json)
         traffic, traffic_src = None, None
         dom = max(table, key=lambda k: table[k]["total_ms"])
-        for fname in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+        for fname in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fname)) as fh:
                     tj = json.load(fh)

@@ -138,6 +138,31 @@ def test_other_architectures_match_oracle(gpu_device, hidden, heads, layers, ffn
         assert _lib.lib().bd_backbone_mega_supported(C.byref(bbg.packed().desc), L) == 1
 
 
+def test_stress_backbone_at_full_depth_matches_oracle(gpu_device):
+    """The stress configuration as bench.py runs it: 24 layers, d = 1024, ffn 4096, 8 heads of 128, L = 512, bf16
+    (LayerNorm + tiled GEMM + stand-alone attention kernels), two sequences (one ragged) against the fp32 oracle."""
+    cfg = dict(RI.SMALL_CFG, hidden_size=1024, num_heads=8, num_layers=24, ffn_hidden_size=4096,
+               max_position_embeddings=512, dropout=0.0)
+    torch.manual_seed(1)
+    bb = DiffusionBackbone(**cfg).eval()
+    RI.perturb_state_dict(bb.state_dict(), 9)
+    sd = {k: v.clone() for k, v in bb.state_dict().items()}
+    ids, attn, t = (x[[0, 5]].copy() for x in RI.backbone_inputs(cfg, 4, B=6, L=512))
+    attn[1, 300:] = 0
+    ids[1, 300:] = 0
+    ids[1, 299] = 3
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        ref = BR.logits(sd, cfg, torch.from_numpy(ids), torch.from_numpy(t), torch.from_numpy(attn)).numpy()
+        bbg = bb.to(gpu_device)
+        got = bbg(torch.from_numpy(ids).to(gpu_device), torch.from_numpy(t).to(gpu_device),
+                  torch.from_numpy(attn).to(gpu_device)).cpu().numpy()
+    e_max, e_rel = H.logits_errors(got, ref)
+    print(f"\n[24 layers, d=1024, 8x128, L=512 bf16] logits max-norm error {e_max:.2e}, per-element (|ref| >= max/4) {e_rel:.2e}")
+    assert np.isfinite(got).all()
+    assert e_max < BF16_TOL
+
+
 def test_intermediate_hidden_states_match_oracle(gpu_device):
     """get_hidden_states(layer_idx): residual stream after block i, no final norm (-1: final norm)."""
     cfg = dict(RI.SMALL_CFG, num_layers=3, dropout=0.0)
