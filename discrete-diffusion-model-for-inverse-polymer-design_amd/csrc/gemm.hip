@@ -592,6 +592,206 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, T == 4 ?
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// The same 256 x 256 tile with EIGHT waves, two per SIMD, that take turns (ping-pong): waves 0-3 hold the tile's upper
+// 128 activation rows, waves 4-7 the lower 128 (a wave = 128 rows x 64 columns: 8 x 4 accumulators of
+// v_mfma_f32_16x16x32_bf16, 128 registers), and the second group runs one barrier behind the first, so that on every
+// SIMD one wave issues its 16 MFMAs of a phase while its partner reads operands from LDS and sends LDS-DMA pieces off.
+// A K-tile (64 k-values) is four phases, one per 64 x 32 quadrant of the wave's output:
+//   P1 reads X0 (2 weight tiles) + Y0 (4 activation tiles), P2 reads X1, P3 reads Y1, P4 reads nothing
+//   (quadrants (Y0,X0), (Y0,X1), (Y1,X1), (Y1,X0); every fragment is read from LDS once per K-tile).
+// LDS: two buffers of 64 KB = [Ylo | Yhi | Xlo | Xhi], 128 rows x 128 B each (chunk c of row r at slot c ^ ((r >> 1) & 7):
+// the 16 rows x one k-chunk of an operand read touch every bank once). The buffer of K-tile u is refilled for tile u + 2
+// region by region as soon as no wave reads the region any more, one 16-KB stage per phase (2 pieces per thread):
+//   tile u: P1 -> weights' upper half of tile u + 1, P2 -> activation rows 64-127 (of both halves) of u + 1,
+//           P3 -> activation rows 0-63 of u + 2, P4 -> weights' lower half of u + 2,
+// i.e. every stage is issued 4 to 6 phases before its first read, and 3 to 4 stages are in flight at any time. A wave
+// waits for its own pieces only (vmcnt(6) in P4 for what P1 of the next tile reads, vmcnt(8) in P2 for what P3 reads,
+// each with exactly that many younger pieces behind it: past the last K-tile the stages are still issued, re-reading
+// the last tile's bytes into regions nobody reads, so that the counts hold to the end), and every read of a region comes
+// behind a barrier that all waves pass after that wait. Weight rows are permuted inside the 64-row sub-tiles so that a
+// lane's 16 accumulators of an activation row are 16 consecutive output columns (epilogue_row as in the kernels above).
+constexpr int G8_BUF = 65536;
+
+template <int MH, int XH>
+__device__ __forceinline__ void g8_quadrant(f32x4 (&acc)[8][4], const bf16x8 (&X)[2][2], const bf16x8 (&Y)[4][2]) {
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int sx = 0; sx < 2; ++sx)
+        acc[4 * MH + t][2 * XH + sx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X[sx][kk], Y[t][kk], acc[4 * MH + t][2 * XH + sx], 0, 0, 0);
+}
+
+template <int EPI, bool DROP>
+__global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem8p[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int g = lane >> 4, c = lane & 15;
+  if (EPI == EPI_AXPBY_BF16 || EPI == EPI_BIAS_BF16) {
+    const long long b = blockIdx.y;
+    p.A += b * p.sA;
+    p.W += b * p.sW;
+    p.out = (unsigned short*)p.out + b * p.sOut;
+    if (EPI == EPI_AXPBY_BF16) p.aux_in = (const unsigned short*)p.aux_in + b * p.sOut;
+  }
+  int tile;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q = nwg >> 3, rr = nwg & 7, xcd = orig & 7;
+    tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
+  }
+  const int tiles_n = (p.Npad + 255) / 256, tiles_m = (p.M + 255) / 256;
+  const int per_group = 8 * tiles_n, group = tile / per_group;
+  const int rows_here = min(tiles_m - 8 * group, 8);
+  const int in_group = tile - group * per_group;
+  const int m0 = (8 * group + in_group % rows_here) * 256, n0 = (in_group / rows_here) * 256;
+  const int K = p.K, nt = K >> 6;
+
+  // ---- LDS-DMA: stage kinds 0 = activation rows 0-63 of both halves, 1 = weights' lower half, 2 = weights' upper half,
+  //      3 = activation rows 64-127 of both halves; thread's pieces q = 2 wave + j (j = 0, 1) of the stage's sixteen
+  unsigned voff[4][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = 2 * wave + j, rr = lane >> 3, slot = lane & 7;
+    const int rho = 8 * (q & 7) + rr;                          // row inside the 64-row part of activation half q >> 3 (= wr)
+    const int cha = slot ^ ((rho >> 1) & 7);
+    const int am0 = min(m0 + 128 * (q >> 3) + rho, p.M - 1) - m0, am1 = min(m0 + 128 * (q >> 3) + 64 + rho, p.M - 1) - m0;
+    voff[0][j] = (unsigned)((am0 * K + 8 * cha) * 2);
+    voff[3][j] = (unsigned)((am1 * K + 8 * cha) * 2);
+    const int rx = 8 * q + rr;                                 // LDS row of the 128-row weight half
+    const int i = rx & 15, tn = (rx >> 4) & 3;
+    const int nrel = 64 * (rx >> 6) + 16 * (i >> 2) + 4 * tn + (i & 3);
+    const int chx = slot ^ ((rx >> 1) & 7);
+    const int last = p.Npad - 1 - n0;                          // a half-empty last column tile re-reads the last weight row
+    voff[1][j] = (unsigned)((min(nrel, last) * K + 8 * chx) * 2);
+    voff[2][j] = (unsigned)((min(128 + nrel, last) * K + 8 * chx) * 2);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(voff[k][0]), "+v"(voff[k][1]));
+  const unsigned char* const wtile = (const unsigned char*)(p.W + (size_t)n0 * K);
+  const unsigned char* const atile = (const unsigned char*)(p.A + (size_t)m0 * K);
+  const unsigned lds0 = (unsigned)(size_t)(g256_lds*)smem8p;
+  // LDS destinations of the thread's two pieces per stage kind (wave-uniform)
+  const unsigned dstY = lds0 + wr * 16384 + (2 * wc) * 1024, dstX = lds0 + 32768 + (2 * wave) * 1024;
+  auto glds = [&](const unsigned char* src, unsigned vo, unsigned dst) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(vo), "s"(src) : "memory", "m0");
+  };
+  auto issue = [&](int kind, int kt) {          // stage `kind` of K-tile kt into buffer kt & 1 (past the end: the last tile's bytes)
+    const unsigned bo = (unsigned)(kt & 1) * G8_BUF;
+    const size_t ko = (size_t)min(kt, nt - 1) * 128;
+    const unsigned char* src = ((kind == 0 || kind == 3) ? atile : wtile) + ko;
+    const unsigned dst = kind == 0 ? dstY + bo : kind == 3 ? dstY + 8192 + bo : kind == 1 ? dstX + bo : dstX + 16384 + bo;
+    glds(src, voff[kind][0], dst);
+    glds(src, voff[kind][1], dst + 1024);
+  };
+
+  // ---- operand reads: lane (g, c) reads row 16 tile + c, k-chunk 4 kk + g, which sits in slot (4 kk + g) ^ (c >> 1)
+  const unsigned sl0 = (unsigned)((g ^ (c >> 1)) * 16), sl1 = (unsigned)(((4 + g) ^ (c >> 1)) * 16);
+  const unsigned xrow = lds0 + 32768 + (wc >> 1) * 16384 + (64 * (wc & 1) + c) * 128;
+  const unsigned yrow = lds0 + wr * 16384 + c * 128;
+  bf16x8 X0[2][2], X1[2][2], Y[4][2];
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: tile 0 whole and the first two stages of tile 1; tile 0's first three stages landed
+  issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0); issue(0, 1); issue(1, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();            // the lower group runs one barrier behind
+
+#define G8_RDX(dst, tn, kk, base)                                                                                  \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"((base) + ((kk) ? sl1 : sl0)), "n"((tn) * 2048) : "memory")
+#define G8_RDY(dst, tm, kk, base)                                                                                  \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"((base) + ((kk) ? sl1 : sl0)), "n"((tm) * 2048) : "memory")
+
+  for (int u = 0; u < nt; ++u) {
+    const unsigned bo = (unsigned)(u & 1) * G8_BUF;
+    const unsigned xb = xrow + bo, yb = yrow + bo;
+    // ---- P1: X0, Y0 -> quadrant (Y0, X0)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      G8_RDX(X0[0][kk], 0, kk, xb); G8_RDX(X0[1][kk], 1, kk, xb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      G8_RDY(Y[0][kk], 0, kk, yb); G8_RDY(Y[1][kk], 1, kk, yb); G8_RDY(Y[2][kk], 2, kk, yb); G8_RDY(Y[3][kk], 3, kk, yb);
+    }
+    issue(2, u + 1);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(X0[0][0]), "+v"(X0[0][1]), "+v"(X0[1][0]), "+v"(X0[1][1]), "+v"(Y[0][0]), "+v"(Y[0][1]), "+v"(Y[1][0]),
+                   "+v"(Y[1][1]), "+v"(Y[2][0]), "+v"(Y[2][1]), "+v"(Y[3][0]), "+v"(Y[3][1]));
+    __builtin_amdgcn_s_setprio(1);
+    g8_quadrant<0, 0>(acc, X0, Y);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- P2: X1 -> quadrant (Y0, X1)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      G8_RDX(X1[0][kk], 2, kk, xb); G8_RDX(X1[1][kk], 3, kk, xb);
+    }
+    issue(3, u + 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // own pieces of rows 64-127 of THIS tile (read in P3) landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(X1[0][0]), "+v"(X1[0][1]), "+v"(X1[1][0]), "+v"(X1[1][1]));
+    __builtin_amdgcn_s_setprio(1);
+    g8_quadrant<0, 1>(acc, X1, Y);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- P3: Y1 -> quadrant (Y1, X1)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      G8_RDY(Y[0][kk], 4, kk, yb); G8_RDY(Y[1][kk], 5, kk, yb); G8_RDY(Y[2][kk], 6, kk, yb); G8_RDY(Y[3][kk], 7, kk, yb);
+    }
+    issue(0, u + 2);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(Y[0][0]), "+v"(Y[0][1]), "+v"(Y[1][0]), "+v"(Y[1][1]), "+v"(Y[2][0]), "+v"(Y[2][1]), "+v"(Y[3][0]),
+                   "+v"(Y[3][1]));
+    __builtin_amdgcn_s_setprio(1);
+    g8_quadrant<1, 1>(acc, X1, Y);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- P4: quadrant (Y1, X0); what P1 of the next tile reads has landed when this wait returns
+    issue(1, u + 2);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+    g8_quadrant<1, 0>(acc, X0, Y);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+  }
+#undef G8_RDX
+#undef G8_RDY
+  if (wr == 0) __builtin_amdgcn_s_barrier();            // the barrier the lower group is behind
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stages past the last tile: no piece may land after the workgroup has gone
+
+  // ---- epilogue: accumulator (tm, tn), register j = row m0 + 128 wr + 16 tm + c, column n0 + 64 wc + 16 g + 4 tn + j
+  const int nb = n0 + 64 * wc + 16 * g;
+  if (nb < p.Npad) {
+    float bv[16];
+    load_bias16<EPI>(p, nb, bv);
+#pragma unroll
+    for (int tm = 0; tm < 8; ++tm) {
+      const int m = m0 + 128 * wr + 16 * tm + c;
+      if (m >= p.M) continue;
+      float v[16];
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 * tn + j] = acc[tm][tn][j] + bv[4 * tn + j];
+      epilogue_row<EPI, DROP>(p, m, nb, v);
+    }
+  }
+}
+
 // Persistent grid: two workgroups per CU (what the kernel's registers and 64 KB of LDS allow), a
 // multiple of 8 so that logical tile ids keep their XCD; fewer tiles than that: one workgroup each.
 int persistent_grid(int n_tiles) {
@@ -617,6 +817,14 @@ bool use_gemm256(const GemmArgs& a) {
   if (a.K < 768) return false;        // few k-steps: the 128 x 128 kernel with two workgroups per CU hides its epilogue better
   return (((long long)a.M + 255) / 256) * ((a.Npad + 255) / 256) >= 128;
 }
+// the eight-wave form of the large tile: same shapes as use_gemm256, K a multiple of 64 (BD_GEMM8P=0: off, 2: every
+// shape that fits, for tests)
+bool use_gemm8p(const GemmArgs& a) {
+  static int mode = getenv("BD_GEMM8P") ? atoi(getenv("BD_GEMM8P")) : 1;
+  if (!mode || a.n_real != a.Npad || a.K % 64 != 0 || a.K < 128) return false;
+  if (mode == 2) return true;
+  return use_gemm256(a);
+}
 // the deep-ring 128 x 128 kernel: a long K on at most one tile per CU (3-7 % there, 20-40 % slower beyond)
 bool use_gemm128_ring(const GemmArgs& a) {
   static int mode = getenv("BD_GEMM128_RING") ? atoi(getenv("BD_GEMM128_RING")) : 1;
@@ -628,7 +836,11 @@ bool use_gemm128_ring(const GemmArgs& a) {
 template <int EPI, bool DROP = false>
 int launch(const GemmArgs& a, hipStream_t s) {
   void* tok = bd_prof_on() ? bd_prof_begin(s) : nullptr;
-  if (use_gemm256(a)) {
+  if (use_gemm8p(a)) {
+    const long long nt = (((long long)a.M + 255) / 256) * ((a.Npad + 255) / 256);
+    BD_SET_MAX_LDS((gemm8p_kernel<EPI, DROP>), 2 * G8_BUF);
+    hipLaunchKernelGGL((gemm8p_kernel<EPI, DROP>), dim3((unsigned)nt), dim3(512), 2 * G8_BUF, s, a);
+  } else if (use_gemm256(a)) {
     const long long nt = (((long long)a.M + 255) / 256) * ((a.Npad + 255) / 256);
     BD_SET_MAX_LDS((gemm256_kernel<EPI, DROP, 4, 4>), 4 * G256_STAGE);
     hipLaunchKernelGGL((gemm256_kernel<EPI, DROP, 4, 4>), dim3((unsigned)nt), dim3(256), 4 * G256_STAGE, s, a);
