@@ -638,55 +638,79 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs p) {
     p.out = (unsigned short*)p.out + b * p.sOut;
     if (EPI == EPI_AXPBY_BF16) p.aux_in = (const unsigned short*)p.aux_in + b * p.sOut;
   }
-  int tile;
-  {
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int q = nwg >> 3, rr = nwg & 7, xcd = orig & 7;
-    tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (orig >> 3);
-  }
+  // The workgroup's tiles: the logical tile list is cut into 8 contiguous chunks, one per group of workgroups that
+  // share an XCD (blockIdx & 7); inside a chunk workgroup j of the gx on that XCD takes tiles j, j + gx, j + 2 gx, ...
+  // (a grid of one workgroup per tile gives every workgroup exactly one). Logical tiles run in groups of 8 tile rows,
+  // column by column inside a group, so that the tiles an XCD works on at a time share operand panels in its L2.
   const int tiles_n = (p.Npad + 255) / 256, tiles_m = (p.M + 255) / 256;
-  const int per_group = 8 * tiles_n, group = tile / per_group;
-  const int rows_here = min(tiles_m - 8 * group, 8);
-  const int in_group = tile - group * per_group;
-  const int m0 = (8 * group + in_group % rows_here) * 256, n0 = (in_group / rows_here) * 256;
+  int tile, tile_end, tile_step;
+  {
+    const int n_all = tiles_m * tiles_n, nwg = gridDim.x, xcd = blockIdx.x & 7;
+    const int q = n_all >> 3, rr = n_all & 7;
+    const int chunk0 = xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q;
+    tile_end = chunk0 + q + (xcd < rr ? 1 : 0);
+    tile_step = (nwg >> 3) + (xcd < (nwg & 7) ? 1 : 0);
+    tile = chunk0 + (blockIdx.x >> 3);
+  }
   const int K = p.K, nt = K >> 6;
+  const int per_group = 8 * tiles_n;
 
   // ---- LDS-DMA: stage kinds 0 = activation rows 0-63 of both halves, 1 = weights' lower half, 2 = weights' upper half,
-  //      3 = activation rows 64-127 of both halves; thread's pieces q = 2 wave + j (j = 0, 1) of the stage's sixteen
-  unsigned voff[4][2];
+  //      3 = activation rows 64-127 of both halves; thread's pieces q = 2 wave + j (j = 0, 1) of the stage's sixteen.
+  //      Source of a tile: base pointers of its activation and weight rows and the thread's byte offsets per stage kind.
+  struct Src {
+    const unsigned char *a, *w;
+    unsigned v[4][2];
+    int m0, n0;
+  };
+  auto make_src = [&](int t, Src& s) {
+    const int group = t / per_group, rows_here = min(tiles_m - 8 * group, 8), in_group = t - group * per_group;
+    const int m0 = (8 * group + in_group % rows_here) * 256, n0 = (in_group / rows_here) * 256;
+    s.m0 = m0;
+    s.n0 = n0;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int q = 2 * wave + j, rr = lane >> 3, slot = lane & 7;
-    const int rho = 8 * (q & 7) + rr;                          // row inside the 64-row part of activation half q >> 3 (= wr)
-    const int cha = slot ^ ((rho >> 1) & 7);
-    const int am0 = min(m0 + 128 * (q >> 3) + rho, p.M - 1) - m0, am1 = min(m0 + 128 * (q >> 3) + 64 + rho, p.M - 1) - m0;
-    voff[0][j] = (unsigned)((am0 * K + 8 * cha) * 2);
-    voff[3][j] = (unsigned)((am1 * K + 8 * cha) * 2);
-    const int rx = 8 * q + rr;                                 // LDS row of the 128-row weight half
-    const int i = rx & 15, tn = (rx >> 4) & 3;
-    const int nrel = 64 * (rx >> 6) + 16 * (i >> 2) + 4 * tn + (i & 3);
-    const int chx = slot ^ ((rx >> 1) & 7);
-    const int last = p.Npad - 1 - n0;                          // a half-empty last column tile re-reads the last weight row
-    voff[1][j] = (unsigned)((min(nrel, last) * K + 8 * chx) * 2);
-    voff[2][j] = (unsigned)((min(128 + nrel, last) * K + 8 * chx) * 2);
-  }
+    for (int j = 0; j < 2; ++j) {
+      const int q = 2 * wave + j, rr = lane >> 3, slot = lane & 7;
+      const int rho = 8 * (q & 7) + rr;                          // row inside the 64-row part of activation half q >> 3 (= wr)
+      const int cha = slot ^ ((rho >> 1) & 7);
+      const int am0 = min(m0 + 128 * (q >> 3) + rho, p.M - 1) - m0, am1 = min(m0 + 128 * (q >> 3) + 64 + rho, p.M - 1) - m0;
+      s.v[0][j] = (unsigned)((am0 * K + 8 * cha) * 2);
+      s.v[3][j] = (unsigned)((am1 * K + 8 * cha) * 2);
+      const int rx = 8 * q + rr;                                 // LDS row of the 128-row weight half
+      const int i = rx & 15, tn = (rx >> 4) & 3;
+      const int nrel = 64 * (rx >> 6) + 16 * (i >> 2) + 4 * tn + (i & 3);
+      const int chx = slot ^ ((rx >> 1) & 7);
+      const int last = p.Npad - 1 - n0;                          // a half-empty last column tile re-reads the last weight row
+      s.v[1][j] = (unsigned)((min(nrel, last) * K + 8 * chx) * 2);
+      s.v[2][j] = (unsigned)((min(128 + nrel, last) * K + 8 * chx) * 2);
+    }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(voff[k][0]), "+v"(voff[k][1]));
-  const unsigned char* const wtile = (const unsigned char*)(p.W + (size_t)n0 * K);
-  const unsigned char* const atile = (const unsigned char*)(p.A + (size_t)m0 * K);
+    for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(s.v[k][0]), "+v"(s.v[k][1]));
+    s.w = (const unsigned char*)(p.W + (size_t)n0 * K);
+    s.a = (const unsigned char*)(p.A + (size_t)m0 * K);
+  };
+  Src cur, nxt;                         // the tile being multiplied and the one after it (the stage stream runs two K-tiles ahead)
+  make_src(tile, cur);
+  bool more = tile + tile_step < tile_end;
+  if (more) make_src(tile + tile_step, nxt); else nxt = cur;      // no next tile: the stages past the end re-read this one's first bytes
+  int kbase = 0;                        // K-tiles of earlier tiles: buffer parity runs on through the tile sequence
+
   const unsigned lds0 = (unsigned)(size_t)(g256_lds*)smem8p;
   // LDS destinations of the thread's two pieces per stage kind (wave-uniform)
   const unsigned dstY = lds0 + wr * 16384 + (2 * wc) * 1024, dstX = lds0 + 32768 + (2 * wave) * 1024;
   auto glds = [&](const unsigned char* src, unsigned vo, unsigned dst) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(vo), "s"(src) : "memory", "m0");
   };
-  auto issue = [&](int kind, int kt) {          // stage `kind` of K-tile kt into buffer kt & 1 (past the end: the last tile's bytes)
-    const unsigned bo = (unsigned)(kt & 1) * G8_BUF;
-    const size_t ko = (size_t)min(kt, nt - 1) * 128;
-    const unsigned char* src = ((kind == 0 || kind == 3) ? atile : wtile) + ko;
+  // stage `kind` of K-tile kt of the current tile; kt >= nt: K-tile kt - nt of the next one (nt >= 2, so kt - nt <= 1)
+  auto issue = [&](int kind, int kt) {
+    const unsigned bo = (unsigned)((kbase + kt) & 1) * G8_BUF;
+    const bool over = kt >= nt;
+    const size_t ko = (size_t)(over ? kt - nt : kt) * 128;
+    const bool act = kind == 0 || kind == 3;
+    const unsigned char* src = (over ? (act ? nxt.a : nxt.w) : (act ? cur.a : cur.w)) + ko;
     const unsigned dst = kind == 0 ? dstY + bo : kind == 3 ? dstY + 8192 + bo : kind == 1 ? dstX + bo : dstX + 16384 + bo;
-    glds(src, voff[kind][0], dst);
-    glds(src, voff[kind][1], dst + 1024);
+    glds(src, over ? nxt.v[kind][0] : cur.v[kind][0], dst);
+    glds(src, over ? nxt.v[kind][1] : cur.v[kind][1], dst + 1024);
   };
 
   // ---- operand reads: lane (g, c) reads row 16 tile + c, k-chunk 4 kk + g, which sits in slot (4 kk + g) ^ (c >> 1)
@@ -695,12 +719,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs p) {
   const unsigned yrow = lds0 + wr * 16384 + c * 128;
   bf16x8 X0[2][2], X1[2][2], Y[4][2];
   f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // ---- prologue: tile 0 whole and the first two stages of tile 1; tile 0's first three stages landed
+  // ---- prologue: K-tile 0 whole and the first two stages of K-tile 1; K-tile 0's first three stages landed
   issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0); issue(0, 1); issue(1, 1);
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -711,85 +731,102 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs p) {
 #define G8_RDY(dst, tm, kk, base)                                                                                  \
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"((base) + ((kk) ? sl1 : sl0)), "n"((tm) * 2048) : "memory")
 
-  for (int u = 0; u < nt; ++u) {
-    const unsigned bo = (unsigned)(u & 1) * G8_BUF;
-    const unsigned xb = xrow + bo, yb = yrow + bo;
-    // ---- P1: X0, Y0 -> quadrant (Y0, X0)
+  for (;;) {
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      G8_RDX(X0[0][kk], 0, kk, xb); G8_RDX(X0[1][kk], 1, kk, xb);
-    }
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      G8_RDY(Y[0][kk], 0, kk, yb); G8_RDY(Y[1][kk], 1, kk, yb); G8_RDY(Y[2][kk], 2, kk, yb); G8_RDY(Y[3][kk], 3, kk, yb);
-    }
-    issue(2, u + 1);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(X0[0][0]), "+v"(X0[0][1]), "+v"(X0[1][0]), "+v"(X0[1][1]), "+v"(Y[0][0]), "+v"(Y[0][1]), "+v"(Y[1][0]),
-                   "+v"(Y[1][1]), "+v"(Y[2][0]), "+v"(Y[2][1]), "+v"(Y[3][0]), "+v"(Y[3][1]));
-    __builtin_amdgcn_s_setprio(1);
-    g8_quadrant<0, 0>(acc, X0, Y);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_s_barrier();
-    // ---- P2: X1 -> quadrant (Y0, X1)
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < nt; ++u) {
+      const unsigned bo = (unsigned)((kbase + u) & 1) * G8_BUF;
+      const unsigned xb = xrow + bo, yb = yrow + bo;
+      // ---- P1: X0, Y0 -> quadrant (Y0, X0)
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      G8_RDX(X1[0][kk], 2, kk, xb); G8_RDX(X1[1][kk], 3, kk, xb);
-    }
-    issue(3, u + 1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // own pieces of rows 64-127 of THIS tile (read in P3) landed
-    __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(X1[0][0]), "+v"(X1[0][1]), "+v"(X1[1][0]), "+v"(X1[1][1]));
-    __builtin_amdgcn_s_setprio(1);
-    g8_quadrant<0, 1>(acc, X1, Y);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_s_barrier();
-    // ---- P3: Y1 -> quadrant (Y1, X1)
+      for (int kk = 0; kk < 2; ++kk) {
+        G8_RDX(X0[0][kk], 0, kk, xb); G8_RDX(X0[1][kk], 1, kk, xb);
+      }
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      G8_RDY(Y[0][kk], 4, kk, yb); G8_RDY(Y[1][kk], 5, kk, yb); G8_RDY(Y[2][kk], 6, kk, yb); G8_RDY(Y[3][kk], 7, kk, yb);
+      for (int kk = 0; kk < 2; ++kk) {
+        G8_RDY(Y[0][kk], 0, kk, yb); G8_RDY(Y[1][kk], 1, kk, yb); G8_RDY(Y[2][kk], 2, kk, yb); G8_RDY(Y[3][kk], 3, kk, yb);
+      }
+      issue(2, u + 1);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(X0[0][0]), "+v"(X0[0][1]), "+v"(X0[1][0]), "+v"(X0[1][1]), "+v"(Y[0][0]), "+v"(Y[0][1]), "+v"(Y[1][0]),
+                     "+v"(Y[1][1]), "+v"(Y[2][0]), "+v"(Y[2][1]), "+v"(Y[3][0]), "+v"(Y[3][1]));
+      __builtin_amdgcn_s_setprio(1);
+      g8_quadrant<0, 0>(acc, X0, Y);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+      // ---- P2: X1 -> quadrant (Y0, X1)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        G8_RDX(X1[0][kk], 2, kk, xb); G8_RDX(X1[1][kk], 3, kk, xb);
+      }
+      issue(3, u + 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // own pieces of rows 64-127 of THIS K-tile (read in P3) landed
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(X1[0][0]), "+v"(X1[0][1]), "+v"(X1[1][0]), "+v"(X1[1][1]));
+      __builtin_amdgcn_s_setprio(1);
+      g8_quadrant<0, 1>(acc, X1, Y);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+      // ---- P3: Y1 -> quadrant (Y1, X1)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        G8_RDY(Y[0][kk], 4, kk, yb); G8_RDY(Y[1][kk], 5, kk, yb); G8_RDY(Y[2][kk], 6, kk, yb); G8_RDY(Y[3][kk], 7, kk, yb);
+      }
+      issue(0, u + 2);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(Y[0][0]), "+v"(Y[0][1]), "+v"(Y[1][0]), "+v"(Y[1][1]), "+v"(Y[2][0]), "+v"(Y[2][1]), "+v"(Y[3][0]),
+                     "+v"(Y[3][1]));
+      __builtin_amdgcn_s_setprio(1);
+      g8_quadrant<1, 1>(acc, X1, Y);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+      // ---- P4: quadrant (Y1, X0); what P1 of the next K-tile reads has landed when this wait returns
+      issue(1, u + 2);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+      g8_quadrant<1, 0>(acc, X0, Y);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
     }
-    issue(0, u + 2);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(Y[0][0]), "+v"(Y[0][1]), "+v"(Y[1][0]), "+v"(Y[1][1]), "+v"(Y[2][0]), "+v"(Y[2][1]), "+v"(Y[3][0]),
-                   "+v"(Y[3][1]));
-    __builtin_amdgcn_s_setprio(1);
-    g8_quadrant<1, 1>(acc, X1, Y);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_s_barrier();
-    // ---- P4: quadrant (Y1, X0); what P1 of the next tile reads has landed when this wait returns
-    issue(1, u + 2);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_s_setprio(1);
-    g8_quadrant<1, 0>(acc, X0, Y);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_s_barrier();
+
+    // ---- the tile's output: accumulator (tm, tn), register j = row m0 + 128 wr + 16 tm + c, column n0 + 64 wc + 16 g + 4 tn + j.
+    // The next tile's first stages are in flight or landed meanwhile. The loads and stores here are older than every later
+    // stage piece, and loads complete in order: the counted waits of the K-loop stay sufficient (a store still on its way
+    // can only make them wait longer). No barrier in here: the two groups keep their one-barrier distance.
+    {
+      const int nb = cur.n0 + 64 * wc + 16 * g;
+      if (nb < p.Npad) {
+        float bv[16];
+        load_bias16<EPI>(p, nb, bv);
+#pragma unroll
+        for (int tm = 0; tm < 8; ++tm) {
+          const int m = cur.m0 + 128 * wr + 16 * tm + c;
+          if (m >= p.M) continue;
+          float v[16];
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[4 * tn + j] = acc[tm][tn][j] + bv[4 * tn + j];
+          epilogue_row<EPI, DROP>(p, m, nb, v);
+        }
+      }
+    }
+    if (!more) break;
+    kbase += nt;
+    tile += tile_step;
+    cur = nxt;
+    more = tile + tile_step < tile_end;
+    if (more) make_src(tile + tile_step, nxt);
   }
 #undef G8_RDX
 #undef G8_RDY
   if (wr == 0) __builtin_amdgcn_s_barrier();            // the barrier the lower group is behind
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stages past the last tile: no piece may land after the workgroup has gone
-
-  // ---- epilogue: accumulator (tm, tn), register j = row m0 + 128 wr + 16 tm + c, column n0 + 64 wc + 16 g + 4 tn + j
-  const int nb = n0 + 64 * wc + 16 * g;
-  if (nb < p.Npad) {
-    float bv[16];
-    load_bias16<EPI>(p, nb, bv);
-#pragma unroll
-    for (int tm = 0; tm < 8; ++tm) {
-      const int m = m0 + 128 * wr + 16 * tm + c;
-      if (m >= p.M) continue;
-      float v[16];
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[4 * tn + j] = acc[tm][tn][j] + bv[4 * tn + j];
-      epilogue_row<EPI, DROP>(p, m, nb, v);
-    }
-  }
 }
 
 // Persistent grid: two workgroups per CU (what the kernel's registers and 64 KB of LDS allow), a
@@ -817,6 +854,17 @@ bool use_gemm256(const GemmArgs& a) {
   if (a.K < 768) return false;        // few k-steps: the 128 x 128 kernel with two workgroups per CU hides its epilogue better
   return (((long long)a.M + 255) / 256) * ((a.Npad + 255) / 256) >= 128;
 }
+// workgroups of the eight-wave kernel: one per CU (128 KB of LDS each), a multiple of 8 so that the workgroups of an
+// XCD split the tile list evenly; more tiles than that: every workgroup walks through several (BD_GEMM8P_SLOTS=0: one
+// workgroup per tile)
+int gemm8p_slots() {
+  int dev = 0, ncu = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+  int slots = ncu / 8 * 8;
+  if (const char* e = getenv("BD_GEMM8P_SLOTS")) slots = atoi(e) > 0 ? atoi(e) / 8 * 8 : 0x7fffffff;
+  return slots < 8 ? 8 : slots;
+}
 // the eight-wave form of the large tile: same shapes as use_gemm256, K a multiple of 64 (BD_GEMM8P=0: off, 2: every
 // shape that fits, for tests)
 bool use_gemm8p(const GemmArgs& a) {
@@ -838,8 +886,9 @@ int launch(const GemmArgs& a, hipStream_t s) {
   void* tok = bd_prof_on() ? bd_prof_begin(s) : nullptr;
   if (use_gemm8p(a)) {
     const long long nt = (((long long)a.M + 255) / 256) * ((a.Npad + 255) / 256);
+    static int slots = gemm8p_slots();
     BD_SET_MAX_LDS((gemm8p_kernel<EPI, DROP>), 2 * G8_BUF);
-    hipLaunchKernelGGL((gemm8p_kernel<EPI, DROP>), dim3((unsigned)nt), dim3(512), 2 * G8_BUF, s, a);
+    hipLaunchKernelGGL((gemm8p_kernel<EPI, DROP>), dim3((unsigned)(nt < slots ? nt : slots)), dim3(512), 2 * G8_BUF, s, a);
   } else if (use_gemm256(a)) {
     const long long nt = (((long long)a.M + 255) / 256) * ((a.Npad + 255) / 256);
     BD_SET_MAX_LDS((gemm256_kernel<EPI, DROP, 4, 4>), 4 * G256_STAGE);
