@@ -722,7 +722,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs p) {
 
   // ---- prologue: K-tile 0 whole and the first two stages of K-tile 1; K-tile 0's first three stages landed
   issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0); issue(0, 1); issue(1, 1);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // K-tile 0 whole (its rows 64-127 too: see P2 below)
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();            // the lower group runs one barrier behind
 
@@ -763,7 +763,10 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs p) {
         G8_RDX(X1[0][kk], 2, kk, xb); G8_RDX(X1[1][kk], 3, kk, xb);
       }
       issue(3, u + 1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // own pieces of rows 64-127 of THIS K-tile (read in P3) landed
+      // own pieces of rows 64-127 of THIS K-tile (read in P3) landed. A tile's first K-tile is whole before the tile
+      // begins (prologue; wait in front of the previous tile's stores), and a counted wait here would also wait for
+      // those stores, which are younger than the pieces in question and slow when every CU writes its tile at once
+      if (u > 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(X1[0][0]), "+v"(X1[0][1]), "+v"(X1[1][0]), "+v"(X1[1][1]));
       __builtin_amdgcn_s_setprio(1);
@@ -799,6 +802,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs p) {
     // stage piece, and loads complete in order: the counted waits of the K-loop stay sufficient (a store still on its way
     // can only make them wait longer). No barrier in here: the two groups keep their one-barrier distance.
     {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every stage piece issued so far has landed before the first store goes out
       const int nb = cur.n0 + 64 * wc + 16 * g;
       if (nb < p.Npad) {
         float bv[16];
