@@ -41,6 +41,7 @@ class LayerWeights(C.Structure):
         ("w_fc1_ln", VP), ("b_fc1_ln", VP),
         ("ffn_pack", VP),
         ("attn_pack", VP), ("b_q_attn", VP), ("b_o_fold", VP),
+        ("cs_qkv_ln", VP), ("cs_fc1_ln", VP),
     ]
 
 
@@ -122,6 +123,10 @@ SIGNATURES = {
     "bd_attention_f32": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "bd_gemm_bf16": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "bd_gemm_bf16_aux": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
+    "bd_gemm_deferred_ln_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "bd_gemm_resid_stats_part_bytes": (C.c_longlong, [C.c_int, C.c_int]),
+    "bd_gemm_bf16_resid_stats": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_float, VP]),
+    "bd_gemm_bf16_deferred_ln": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "bd_masked_ce_fwd": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, VP]),
     "bd_masked_ce_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, VP]),
     "bd_layernorm_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, VP]),

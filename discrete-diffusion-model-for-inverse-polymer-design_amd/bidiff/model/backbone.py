@@ -201,8 +201,14 @@ class DiffusionBackbone(nn.Module):
         self.__dict__["_param_cache"] = None
         return super()._apply(fn, *args, **kwargs)
 
+    # True: large models (per-layer kernels on the eight-wave GEMM) run LayerNorm deferred across the residual
+    # projections (bd_gemm_bf16_deferred_ln) instead of a LayerNorm kernel in front of every projection. Off by default:
+    # measured on the medium / large sizes and the 24-layer stress model it takes the same time (what the LayerNorm
+    # kernels cost moves into the projections' epilogues), and it rounds the rows before the mean is taken out.
+    defer_layernorm = False
+
     def _pack_key(self):
-        return (_lib.weights_generation(),) + tuple((p.data_ptr(), p._version) for p in self._params())
+        return (_lib.weights_generation(), self.defer_layernorm) + tuple((p.data_ptr(), p._version) for p in self._params())
 
     def packed(self) -> _Packed:
         """bf16 weight copies and the bd_backbone_desc; rebuilt when any parameter changed."""
@@ -270,8 +276,13 @@ class DiffusionBackbone(nn.Module):
                 lw.w_fc2 = bf(blk.ffn.fc2.weight).data_ptr(); lw.b_fc2 = f32(blk.ffn.fc2.bias).data_ptr()
                 # LayerNorm folded into the following projection: LN(x) W^T + b =
                 # ((x - mean) * rstd) (W * gamma)^T + (b + W beta)   (fp32 fold, then one bf16 rounding)
-                lw.w_qkv_ln = bf(wq32 * blk.norm1.weight.float()[None, :]).data_ptr()
+                wqln = bf(wq32 * blk.norm1.weight.float()[None, :])
+                lw.w_qkv_ln = wqln.data_ptr()
                 lw.b_qkv_ln = f32(bqkv + wq32 @ blk.norm1.bias.float()).data_ptr()
+                # row sums of the folded weights AS ROUNDED (the deferred LayerNorm subtracts mean * these from what
+                # the matrix cores accumulated over the same bf16 values)
+                if self.defer_layernorm:
+                    lw.cs_qkv_ln = f32(wqln.float().sum(dim=1)).data_ptr()
                 # weight stream of the fused attention block: q rows (and bias) also carry the
                 # softmax scale log2(e) / sqrt(head_dim), see attn_block.hip
                 if L_.bd_attn_block_supported(d, self.num_heads, 1) and L_.bd_attn_block_width(d, self.num_heads) == aw:
@@ -294,6 +305,8 @@ class DiffusionBackbone(nn.Module):
                 w1 = blk.ffn.fc1.weight.float()
                 w1ln = bf(w1 * blk.norm2.weight.float()[None, :])
                 lw.w_fc1_ln = w1ln.data_ptr()
+                if self.defer_layernorm:
+                    lw.cs_fc1_ln = f32(w1ln.float().sum(dim=1)).data_ptr()
                 lw.b_fc1_ln = f32(blk.ffn.fc1.bias.float() + w1 @ blk.norm2.bias.float()).data_ptr()
                 # weight stream of the fused feed-forward kernel (fragment order, see ffn_fused.hip); it computes GELU
                 # and the second product in f16, which not every weight set fits: such layers keep the bf16 kernels

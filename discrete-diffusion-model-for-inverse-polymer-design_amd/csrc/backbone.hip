@@ -8,7 +8,7 @@ namespace {
 inline long long align256(long long x) { return (x + 255) & ~255ll; }
 
 struct Carve {
-  long long x, h, qkv, att, ff, total;
+  long long x, h, qkv, att, ff, part, stats, total;
 };
 
 Carve carve(const bd_backbone_desc& c, long long M) {
@@ -20,6 +20,8 @@ Carve carve(const bd_backbone_desc& c, long long M) {
   w.qkv = off; off += align256(M * 3 * aw * 2);     // fused q|k|v bf16 (heads padded to 32 / 64 / 128)
   w.att = off; off += align256(M * aw * 2);         // attention output bf16
   w.ff = off;  off += align256(M * c.ffn * 2);      // GELU(fc1) bf16
+  w.part = off; off += align256((c.d / 64 + 1) * M * 8);   // LayerNorm sums per 64-column block of the residual rows
+  w.stats = off; off += align256(M * 8);            // (mean, 1 / std) per row
   w.total = off;
   return w;
 }
@@ -95,8 +97,42 @@ int forward_impl(const bd_backbone_desc* desc, const long long* ids, const long 
   const bool pan_fc1 = bd_gemm_panel_supported(F, d, 1) != 0;
   const bool fused_ffn = bd_ffn_fused_supported(d, F) != 0;
   const bool fused_attn = bd_attn_block_supported(d, c.n_heads, L) != 0 && aw == bd_attn_block_width(d, c.n_heads);
+  // LayerNorm deferred across the residual projections (large models on the eight-wave GEMM): the projection that
+  // updates the residual rows also leaves their bf16 copy and their row sums, and the next projection multiplies the
+  // raw rows by the gamma-folded weights and normalises in its epilogue, LN(x) W^T = rstd (x W^T - mean colsum(W)).
+  // No LayerNorm kernel between the layers then (the first one, behind the embeddings, and the final one remain).
+  float* part = (float*)(ws + w.part);
+  float* stats = (float*)(ws + w.stats);
+  bool defer = !fused_attn && !fused_ffn && bd_gemm_deferred_ln_supported(Mi, d, aw) && bd_gemm_deferred_ln_supported(Mi, d, F) &&
+               bd_gemm_deferred_ln_supported(Mi, 3 * aw, d) && bd_gemm_deferred_ln_supported(Mi, F, d);
+  for (int i = 0; i < n_run && defer; ++i) {
+    const bd_layer_weights& lw = c.layers[i];
+    defer = lw.w_qkv_ln && lw.b_qkv_ln && lw.cs_qkv_ln && lw.w_fc1_ln && lw.b_fc1_ln && lw.cs_fc1_ln;
+  }
+  bool have_stats = false;      // h holds the bf16 copy of x and stats its row statistics
   for (int i = 0; i < n_run; ++i) {
     const bd_layer_weights& lw = c.layers[i];
+    if (defer) {
+      // ---- x += out_proj(attention(ln1(x)))
+      if (have_stats) {
+        rc = bd_gemm_bf16_deferred_ln(h, lw.w_qkv_ln, lw.b_qkv_ln, lw.cs_qkv_ln, stats, qkv, Mi, 3 * aw, d, 0, stream);
+      } else {
+        if ((rc = bd_layernorm(x, lw.ln1_g, lw.ln1_b, h, nullptr, nullptr, Mi, d, c.ln_eps, stream))) return rc;
+        rc = bd_gemm_bf16(h, lw.w_qkv, lw.b_qkv, qkv, Mi, 3 * aw, 3 * aw, d, 3 * aw, 0, stream);
+      }
+      if (rc) return rc;
+      if ((rc = bd_attention_fwd(qkv, keymask, att, nullptr, B, L, c.n_heads, aw / c.n_heads, stream))) return rc;
+      if ((rc = bd_gemm_bf16_resid_stats(att, lw.w_o, lw.b_o, x, h, part, stats, Mi, d, aw, c.ln_eps, stream))) return rc;
+      // ---- x += fc2(gelu(fc1(ln2(x))))
+      if ((rc = bd_gemm_bf16_deferred_ln(h, lw.w_fc1_ln, lw.b_fc1_ln, lw.cs_fc1_ln, stats, ff, Mi, F, d, 1, stream))) return rc;
+      if (i + 1 < n_run) {
+        if ((rc = bd_gemm_bf16_resid_stats(ff, lw.w_fc2, lw.b_fc2, x, h, part, stats, Mi, d, F, c.ln_eps, stream))) return rc;
+        have_stats = true;
+      } else {
+        if ((rc = bd_gemm_bf16(ff, lw.w_fc2, lw.b_fc2, x, Mi, d, d, F, d, 2, stream))) return rc;
+      }
+      continue;
+    }
     // ---- x += out_proj(attention(ln1(x)))
     if (fused_attn && lw.attn_pack && lw.b_q_attn && lw.b_o_fold) {
       rc = bd_attn_block_fused(x, x, lw.attn_pack, lw.b_q_attn, lw.b_o, lw.b_o_fold, keymask, B, L, d, c.n_heads, c.ln_eps, stream);

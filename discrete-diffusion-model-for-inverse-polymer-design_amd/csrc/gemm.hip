@@ -44,6 +44,11 @@ struct GemmArgs {
   bd_drop_args drop;         // DROP kernels: dropout of the epilogue value at (row m, column n)
   long long sA, sW, sOut;    // batched launch (gridDim.y problems): element strides of A, W and out / aux_in
   float alpha, beta;         // EPI 5
+  // LayerNorm deferred across a residual projection (eight-wave kernel only; all null otherwise):
+  unsigned short* xb_out;    // EPI 2: bf16 copy of the updated residual rows (row stride ldc)
+  float* part_out;           // EPI 2: [Npad / 64][M][2] sum and sum of squares of the updated rows per 64-column block
+  const float* ln_stats;     // EPI 0 / 1: [M][2] mean and 1 / std of the rows of A; value = rstd * (acc - mean * colsum[n]) + bias[n]
+  const float* ln_colsum;    // [Npad] sums of the weight rows
 };
 
 __device__ __forceinline__ int swz_a(int row) { return row & 7; }
@@ -724,7 +729,6 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs p) {
   issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0); issue(0, 1); issue(1, 1);
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // K-tile 0 whole (its rows 64-127 too: see P2 below)
   __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();            // the lower group runs one barrier behind
 
 #define G8_RDX(dst, tn, kk, base)                                                                                  \
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"((base) + ((kk) ? sl1 : sl0)), "n"((tn) * 2048) : "memory")
@@ -736,6 +740,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs p) {
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (wr == 1) __builtin_amdgcn_s_barrier();          // through a tile's K-loop the lower group runs one barrier behind
     for (int u = 0; u < nt; ++u) {
       const unsigned bo = (unsigned)((kbase + u) & 1) * G8_BUF;
       const unsigned xb = xrow + bo, yb = yrow + bo;
@@ -798,25 +803,82 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs p) {
     }
 
     // ---- the tile's output: accumulator (tm, tn), register j = row m0 + 128 wr + 16 tm + c, column n0 + 64 wc + 16 g + 4 tn + j.
-    // The next tile's first stages are in flight or landed meanwhile. The loads and stores here are older than every later
-    // stage piece, and loads complete in order: the counted waits of the K-loop stay sufficient (a store still on its way
-    // can only make them wait longer). No barrier in here: the two groups keep their one-barrier distance.
+    // The upper group waits for the barrier the lower one is behind, so that both groups write their halves at the same
+    // time (one after the other, each would wait for the other's memory latencies). The next tile's first stages are in
+    // flight or landed meanwhile. The loads and stores here are older than every later stage piece, and loads complete in
+    // order: the counted waits of the K-loop stay sufficient (a store still on its way can only make them wait longer).
+    if (wr == 0) __builtin_amdgcn_s_barrier();
     {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every stage piece issued so far has landed before the first store goes out
       const int nb = cur.n0 + 64 * wc + 16 * g;
       if (nb < p.Npad) {
         float bv[16];
         load_bias16<EPI>(p, nb, bv);
+        const bool ln_in = (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16) && p.ln_stats != nullptr;
+        const bool ln_out = EPI == EPI_BIAS_RESID_F32 && !DROP && p.xb_out != nullptr;
+        float cs[16];
+        if (ln_in) {
+#pragma unroll
+          for (int j4 = 0; j4 < 4; ++j4) {
+            const f32x4 t = *(const f32x4*)(p.ln_colsum + nb + 4 * j4);
+            cs[4 * j4 + 0] = t[0]; cs[4 * j4 + 1] = t[1]; cs[4 * j4 + 2] = t[2]; cs[4 * j4 + 3] = t[3];
+          }
+        }
 #pragma unroll
         for (int tm = 0; tm < 8; ++tm) {
           const int m = cur.m0 + 128 * wr + 16 * tm + c;
           if (m >= p.M) continue;
           float v[16];
+          if (ln_in) {
+            // A held the raw rows x (bf16), the weights carry gamma: LN(x) W^T = rstd (x W^T - mean colsum(W))
+            const float mean = p.ln_stats[2 * (size_t)m], rstd = p.ln_stats[2 * (size_t)m + 1];
 #pragma unroll
-          for (int tn = 0; tn < 4; ++tn)
+            for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[4 * tn + j] = acc[tm][tn][j] + bv[4 * tn + j];
-          epilogue_row<EPI, DROP>(p, m, nb, v);
+              for (int j = 0; j < 4; ++j)
+                v[4 * tn + j] = rstd * (acc[tm][tn][j] - mean * cs[4 * tn + j]) + bv[4 * tn + j];
+          } else {
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[4 * tn + j] = acc[tm][tn][j] + bv[4 * tn + j];
+          }
+          if (ln_out) {
+            // the updated residual row segment in fp32, its bf16 copy (the next projection's operand) and its share of
+            // the row's LayerNorm sums: the four lanes of a row (g = 0 .. 3) hold the wave's 64 columns of it
+            float* o = (float*)p.out + (size_t)m * p.ldc + nb;
+            const float* ri = p.aux_in ? (const float*)p.aux_in + (size_t)m * p.ldc + nb : o;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) {
+              f32x4 x = *(const f32x4*)(ri + 4 * j4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                x[e] += v[4 * j4 + e];
+                v[4 * j4 + e] = x[e];
+                s1 += x[e];
+                s2 += x[e] * x[e];
+              }
+              *(f32x4*)(o + 4 * j4) = x;
+            }
+            unsigned short* ob = p.xb_out + (size_t)m * p.ldc + nb;
+            u32x4 lo, hi;
+            lo[0] = bd_pack_bf16x2(v[0], v[1]);   lo[1] = bd_pack_bf16x2(v[2], v[3]);
+            lo[2] = bd_pack_bf16x2(v[4], v[5]);   lo[3] = bd_pack_bf16x2(v[6], v[7]);
+            hi[0] = bd_pack_bf16x2(v[8], v[9]);   hi[1] = bd_pack_bf16x2(v[10], v[11]);
+            hi[2] = bd_pack_bf16x2(v[12], v[13]); hi[3] = bd_pack_bf16x2(v[14], v[15]);
+            *(u32x4*)(ob) = lo;
+            *(u32x4*)(ob + 8) = hi;
+            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (g == 0) {
+              const int blk = (cur.n0 >> 6) + wc;
+              f32x2 st; st[0] = s1; st[1] = s2;
+              *(f32x2*)(p.part_out + ((size_t)blk * p.M + m) * 2) = st;
+            }
+          } else {
+            epilogue_row<EPI, DROP>(p, m, nb, v);
+          }
         }
       }
     }
@@ -829,7 +891,6 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs p) {
   }
 #undef G8_RDX
 #undef G8_RDY
-  if (wr == 0) __builtin_amdgcn_s_barrier();            // the barrier the lower group is behind
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stages past the last tile: no piece may land after the workgroup has gone
 }
 
@@ -928,6 +989,7 @@ extern "C" int bd_gemm_bf16_drop(const void* A, const void* W, const float* bias
   GemmArgs a;
   a.A = (const unsigned short*)A; a.W = (const unsigned short*)W; a.bias = bias; a.out = out;
   a.aux_in = aux_in; a.aux_out = aux_out;
+  a.xb_out = nullptr; a.part_out = nullptr; a.ln_stats = nullptr; a.ln_colsum = nullptr;
   BD_REQUIRE(epilogue != EPI_DGELU_BF16 || aux_in != nullptr, "bd_gemm_bf16: epilogue 4 needs the pre-activation");
   BD_REQUIRE(epilogue != EPI_MUL_AUX_BF16 || aux_in != nullptr, "bd_gemm_bf16: epilogue 7 needs its multiplier");
   BD_REQUIRE(epilogue != EPI_GELU_GRAD_BF16 || aux_out != nullptr, "bd_gemm_bf16: epilogue 6 needs aux_out");
@@ -959,6 +1021,88 @@ extern "C" int bd_gemm_bf16_drop(const void* A, const void* W, const float* bias
     case EPI_MUL_AUX_BF16: return launch<EPI_MUL_AUX_BF16>(a, s);
     default: return bd_fail(BD_ERR_ARG, "bd_gemm_bf16: unknown epilogue %d", epilogue);
   }
+}
+
+// ---- LayerNorm deferred across the residual projections (eight-wave kernel)
+namespace {
+// (mean, 1 / std) of every row from the per-block sums the residual projection left: part [n_blk][M][2]
+__global__ __launch_bounds__(256) void ln_stats_finish_kernel(const float* __restrict__ part, float* __restrict__ stats,
+                                                              int M, int n_blk, float inv_d, float eps) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int b = 0; b < n_blk; ++b) {
+    const f32x2 t = *(const f32x2*)(part + ((size_t)b * M + m) * 2);
+    s1 += t[0];
+    s2 += t[1];
+  }
+  const float mean = s1 * inv_d;
+  const float var = fmaxf(s2 * inv_d - mean * mean, 0.f);
+  f32x2 o; o[0] = mean; o[1] = rsqrtf(var + eps);
+  *(f32x2*)(stats + 2 * (size_t)m) = o;
+}
+
+bool deferred_shape_ok(int M, int N, int K) {
+  return M > 0 && N > 0 && N % BN == 0 && K % 64 == 0 && K >= 128 &&
+         (((long long)M + 255) / 256) * ((N + 255) / 256) < (1ll << 31);
+}
+
+template <int EPI>
+int launch8p(GemmArgs& a, hipStream_t s, const char* what) {
+  a.tiles_n = a.Npad / BN;
+  a.n_tiles = (int)((((long long)a.M + BM - 1) / BM) * a.tiles_n);
+  a.sA = a.sW = a.sOut = 0; a.alpha = 1.f; a.beta = 0.f;
+  bd_drop_make(nullptr, 0u, &a.drop);
+  void* tok = bd_prof_on() ? bd_prof_begin(s) : nullptr;
+  const long long nt = (((long long)a.M + 255) / 256) * ((a.Npad + 255) / 256);
+  static int slots = gemm8p_slots();
+  BD_SET_MAX_LDS((gemm8p_kernel<EPI, false>), 2 * G8_BUF);
+  hipLaunchKernelGGL((gemm8p_kernel<EPI, false>), dim3((unsigned)(nt < slots ? nt : slots)), dim3(512), 2 * G8_BUF, s, a);
+  if (tok) bd_prof_end(tok, s, 2.0 * (double)a.M * (double)a.n_real * (double)a.K);
+  return bd_check_launch(what);
+}
+}  // namespace
+
+// 1 when the forward would run a projection of this shape on the eight-wave kernel anyway (the deferred-LayerNorm
+// entry points always do: the layout of their row sums is that kernel's)
+extern "C" int bd_gemm_deferred_ln_supported(int M, int N, int K) {
+  if (!deferred_shape_ok(M, N, K)) return 0;
+  GemmArgs a{};
+  a.M = M; a.Npad = N; a.n_real = N; a.K = K;
+  return use_gemm8p(a) ? 1 : 0;
+}
+
+extern "C" long long bd_gemm_resid_stats_part_bytes(int M, int N) {
+  return M > 0 && N > 0 ? (long long)((N + 63) / 64) * M * 2 * (long long)sizeof(float) : -1;
+}
+
+extern "C" int bd_gemm_bf16_resid_stats(const void* A, const void* W, const float* bias, float* x, void* xb, float* part,
+                                        float* stats, int M, int N, int K, float eps, void* stream) {
+  BD_REQUIRE(A && W && x && xb && part && stats, "bd_gemm_bf16_resid_stats: null operand");
+  BD_REQUIRE(deferred_shape_ok(M, N, K), "bd_gemm_bf16_resid_stats: M=%d N=%d K=%d (N a multiple of 128, K of 64, K >= 128)", M, N, K);
+  GemmArgs a{};
+  a.A = (const unsigned short*)A; a.W = (const unsigned short*)W; a.bias = bias; a.out = x;
+  a.M = M; a.Npad = N; a.n_real = N; a.K = K; a.ldc = N;
+  a.xb_out = (unsigned short*)xb; a.part_out = part;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = launch8p<EPI_BIAS_RESID_F32>(a, s, "bd_gemm_bf16_resid_stats");
+  if (rc) return rc;
+  hipLaunchKernelGGL(ln_stats_finish_kernel, dim3((M + 255) / 256), dim3(256), 0, s, part, stats, M, N / 64, 1.0f / (float)N, eps);
+  return bd_check_launch("bd_gemm_bf16_resid_stats (row statistics)");
+}
+
+extern "C" int bd_gemm_bf16_deferred_ln(const void* xb, const void* W_ln, const float* bias_ln, const float* colsum,
+                                        const float* stats, void* out, int M, int N, int K, int epilogue, void* stream) {
+  BD_REQUIRE(xb && W_ln && colsum && stats && out, "bd_gemm_bf16_deferred_ln: null operand");
+  BD_REQUIRE(epilogue == EPI_BIAS_BF16 || epilogue == EPI_BIAS_GELU_BF16, "bd_gemm_bf16_deferred_ln: epilogue %d (0 or 1)", epilogue);
+  BD_REQUIRE(deferred_shape_ok(M, N, K), "bd_gemm_bf16_deferred_ln: M=%d N=%d K=%d (N a multiple of 128, K of 64, K >= 128)", M, N, K);
+  GemmArgs a{};
+  a.A = (const unsigned short*)xb; a.W = (const unsigned short*)W_ln; a.bias = bias_ln; a.out = out;
+  a.M = M; a.Npad = N; a.n_real = N; a.K = K; a.ldc = N;
+  a.ln_stats = stats; a.ln_colsum = colsum;
+  hipStream_t s = (hipStream_t)stream;
+  return epilogue == EPI_BIAS_BF16 ? launch8p<EPI_BIAS_BF16>(a, s, "bd_gemm_bf16_deferred_ln")
+                                   : launch8p<EPI_BIAS_GELU_BF16>(a, s, "bd_gemm_bf16_deferred_ln");
 }
 
 // Batched C_b = A_b W_b^T over `batch` problems of one shape (element strides sA, sW, sOut; a zero

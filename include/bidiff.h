@@ -166,6 +166,10 @@ typedef struct bd_layer_weights {
   /* optional weight stream and bias of the fused attention block (bd_attn_pack_weights); null =
    * separate projection / attention / out-proj kernels                                        */
   const void* attn_pack; const float* b_q_attn; const float* b_o_fold;
+  /* optional row sums (fp32, over the input columns) of the bf16 values of w_qkv_ln [3 * attn_width] and w_fc1_ln [F]:
+   * with them (and the folded copies above) large models run LayerNorm deferred across the residual projections,
+   * see bd_gemm_bf16_deferred_ln; null = LayerNorm kernels                                       */
+  const float* cs_qkv_ln; const float* cs_fc1_ln;
 } bd_layer_weights;
 
 typedef struct bd_backbone_desc {
@@ -183,6 +187,28 @@ typedef struct bd_backbone_desc {
    * and pre-scales the q rows by sqrt(padded / true head_dim) (the kernel scales by 1/sqrt(padded)). */
   int attn_width;
 } bd_backbone_desc;
+
+/* LayerNorm deferred across a residual projection, for the shapes the eight-wave 256 x 256 GEMM takes (N a multiple of
+ * 128, K a multiple of 64, K >= 128; bd_gemm_deferred_ln_supported additionally tells whether the plain bd_gemm_bf16
+ * would pick that kernel for the shape: bd_backbone_forward defers only then, and only when every layer carries cs_qkv_ln
+ * and cs_fc1_ln; measured, the forward takes the same time either way).
+ * bd_gemm_bf16_resid_stats: x [M, N] fp32 += A [M, K] W[N, K]^T + bias (the block's residual projection, epilogue 2 of
+ * bd_gemm_bf16), and on the way out xb [M, N] bf16 = the updated rows rounded once, part (scratch of
+ * bd_gemm_resid_stats_part_bytes(M, N) bytes) their sums and sums of squares per 64-column block, stats [M, 2] fp32 =
+ * (mean, 1 / sqrt(biased variance + eps)) of every updated row (a second, small launch).
+ * bd_gemm_bf16_deferred_ln: out [M, N] bf16 = f(LN(x) W^T + b) computed as rstd * (xb W_ln^T - mean * colsum) + bias_ln
+ * with W_ln = W * gamma per input column (bf16), bias_ln = b + W beta, colsum [N] = fp32 row sums of the bf16 values of
+ * W_ln; epilogue 0: f = identity, 1: f = GELU (erf form). The rows enter the matrix cores as bf16(x) instead of
+ * bf16(LN(x)): the rounding error of an element is relative to |x| instead of |x - mean|, the same when the row mean
+ * is small against the row's spread (residual rows of a pre-LN transformer), larger by |mean| / std otherwise.
+ * Together they replace  x = x + proj(...); h = norm(x); y = linear(h)  of TransformerBlock.forward
+ * (src/model/backbone.py:120-129) without a LayerNorm kernel between the two projections. */
+int bd_gemm_deferred_ln_supported(int M, int N, int K);
+long long bd_gemm_resid_stats_part_bytes(int M, int N);
+int bd_gemm_bf16_resid_stats(const void* A, const void* W, const float* bias, float* x, void* xb, float* part,
+                             float* stats, int M, int N, int K, float eps, void* stream);
+int bd_gemm_bf16_deferred_ln(const void* xb, const void* W_ln, const float* bias_ln, const float* colsum,
+                             const float* stats, void* out, int M, int N, int K, int epilogue, void* stream);
 
 /* Bytes of device scratch bd_backbone_forward needs for a [B, L] batch. */
 long long bd_backbone_workspace_bytes(const bd_backbone_desc* desc, int B, int L);

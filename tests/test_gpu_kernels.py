@@ -503,3 +503,77 @@ def test_large_tile_gemm_all_epilogues(gpu_device, M, N, K):
     oi = torch.empty(M, N, device=dev)
     run(3, oi, b=None)
     assert torch.equal(oi.cpu(), Ai @ Wi.t())
+
+
+# ---------------------------------------------------------------- LayerNorm deferred across a residual projection
+@pytest.mark.parametrize("M,d,Kp,Nc,row_mean", [(1000, 768, 3072, 2304, 0.0), (777, 1152, 1152, 4608, 0.0),
+                                                 (512, 1024, 4096, 3072, 2.0)])
+def test_deferred_layernorm_projections(gpu_device, M, d, Kp, Nc, row_mean):
+    """bd_gemm_bf16_resid_stats + bd_gemm_bf16_deferred_ln against the plain chain (epilogue-2 GEMM, LayerNorm, GEMM):
+    the updated residual rows bit for bit, their bf16 copy = one rounding of them, the row statistics against torch, and
+    the next projection's output against fp32 torch at the bound of the plain bf16 chain (looser when the rows carry a
+    mean of row_mean standard deviations: the rows are rounded before the mean is taken out)."""
+    dev = gpu_device
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(M + d)
+    A = (torch.randn(M, Kp, generator=g) * 0.5).bfloat16().to(dev)
+    Wp = (torch.randn(d, Kp, generator=g) / math.sqrt(Kp)).bfloat16().to(dev)
+    bp = (torch.randn(d, generator=g) * 0.2).to(dev)
+    x0 = (torch.randn(M, d, generator=g) * 1.5 + row_mean * 1.5).to(dev)
+    gm = (1 + 0.2 * torch.randn(d, generator=g)).to(dev)
+    bt = (0.3 * torch.randn(d, generator=g)).to(dev)
+    Wc = (torch.randn(Nc, d, generator=g) / math.sqrt(d)).to(dev)
+    bc = (torch.randn(Nc, generator=g) * 0.3).to(dev)
+    # plain chain
+    x_plain = x0.clone()
+    gemm(A, Wp, bp, x_plain, d, 2)
+    # deferred chain
+    x = x0.clone()
+    xb = torch.full((M, d), float("nan"), dtype=torch.bfloat16, device=dev)
+    part = torch.empty(lib.bd_gemm_resid_stats_part_bytes(M, d) // 4, dtype=torch.float32, device=dev)
+    stats = torch.empty(M, 2, dtype=torch.float32, device=dev)
+    _lib.check(lib.bd_gemm_bf16_resid_stats(_lib.ptr(A), _lib.ptr(Wp), _lib.ptr(bp), _lib.ptr(x), _lib.ptr(xb), _lib.ptr(part),
+                                            _lib.ptr(stats), M, d, Kp, 1e-5, _s()), "resid_stats")
+    torch.cuda.synchronize()
+    assert torch.equal(x, x_plain)
+    assert torch.equal(xb, x.bfloat16())
+    mean = x.double().mean(1)
+    rstd = 1.0 / torch.sqrt(x.double().var(1, unbiased=False) + 1e-5)
+    assert float((stats[:, 0].double() - mean).abs().max()) < 1e-5 * (1 + abs(row_mean) * 1.5)
+    assert float(((stats[:, 1].double() - rstd) / rstd).abs().max()) < 1e-4
+    Wln = (Wc * gm[None, :]).bfloat16()
+    bln = (bc + Wc @ bt).contiguous()
+    cs = Wln.float().sum(1).contiguous()
+    for epi in (0, 1):
+        out = torch.full((M, Nc), float("nan"), dtype=torch.bfloat16, device=dev)
+        _lib.check(lib.bd_gemm_bf16_deferred_ln(_lib.ptr(xb), _lib.ptr(Wln), _lib.ptr(bln), _lib.ptr(cs), _lib.ptr(stats),
+                                                _lib.ptr(out), M, Nc, d, epi, _s()), "deferred_ln")
+        ref = torch.nn.functional.layer_norm(x, (d,), gm, bt, 1e-5) @ Wc.t() + bc
+        if epi == 1:
+            ref = torch.nn.functional.gelu(ref)
+        # the plain chain on the same inputs, for the scale of the bf16 error
+        h = torch.empty(M, d, dtype=torch.bfloat16, device=dev)
+        _lib.check(lib.bd_layernorm(_lib.ptr(x), _lib.ptr(gm), _lib.ptr(bt), _lib.ptr(h), None, None, M, d, 1e-5, _s()), "ln")
+        plain = torch.empty(M, Nc, dtype=torch.bfloat16, device=dev)
+        gemm(h, Wc.bfloat16().contiguous(), bc, plain, Nc, epi)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out.float()).all()
+        e_def = float((out.float() - ref).norm() / ref.norm())
+        e_plain = float((plain.float() - ref).norm() / ref.norm())
+        assert e_plain < 6e-3
+        assert e_def < (6e-3 if row_mean == 0.0 else 2e-2), (e_def, e_plain)
+
+
+def test_deferred_layernorm_arguments(gpu_device):
+    lib = _lib.lib()
+    a = torch.zeros(256, 256, dtype=torch.bfloat16, device=gpu_device)
+    f = torch.zeros(256, 256, dtype=torch.float32, device=gpu_device)
+    assert lib.bd_gemm_bf16_resid_stats(_lib.ptr(a), _lib.ptr(a), None, _lib.ptr(f), _lib.ptr(a), _lib.ptr(f), _lib.ptr(f),
+                                        256, 200, 256, 1e-5, _s()) < 0
+    assert lib.bd_gemm_bf16_deferred_ln(_lib.ptr(a), _lib.ptr(a), None, _lib.ptr(f), _lib.ptr(f), _lib.ptr(a), 256, 256, 96, 0,
+                                        _s()) < 0
+    assert lib.bd_gemm_bf16_deferred_ln(_lib.ptr(a), _lib.ptr(a), None, _lib.ptr(f), _lib.ptr(f), _lib.ptr(a), 256, 256, 256, 2,
+                                        _s()) < 0
+    assert lib.bd_gemm_deferred_ln_supported(100000, 768, 768) == 1
+    assert lib.bd_gemm_deferred_ln_supported(1000, 768, 768) == 0      # too few tiles for the large-tile kernel to pay
+    assert lib.bd_gemm_deferred_ln_supported(100000, 768, 96) == 0      # K below 128

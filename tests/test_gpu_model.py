@@ -115,7 +115,8 @@ def test_benchmark_architecture_matches_reference_golden(gpu_device, V, capsys):
     (1024, 16, 2, 4096, 2, 512),   # scaled-up stress shape (d = 1024, L = 512): unfused kernels
     (384, 3, 2, 1536, 3, 200),     # small backbone beyond 128 tokens: fused feed-forward, unfused attention
     (768, 6, 2, 3072, 40, 128),    # the reference's "medium" size (config.yaml model_sizes), 5120 rows
-    (1152, 9, 2, 4608, 60, 128),   # its "large" size: widths that are odd multiples of 128, 7680 rows (large-tile GEMM)
+    (768, 6, 3, 3072, 88, 128),    # medium, 11264 rows: enough tiles for the eight-wave GEMM
+    (1152, 9, 2, 4608, 60, 128),   # its "large" size: widths that are odd multiples of 128, 7680 rows (eight-wave GEMM)
 ])
 def test_other_architectures_match_oracle(gpu_device, hidden, heads, layers, ffn, B, L):
     cfg = dict(RI.SMALL_CFG, hidden_size=hidden, num_heads=heads, num_layers=layers, ffn_hidden_size=ffn,
@@ -136,6 +137,37 @@ def test_other_architectures_match_oracle(gpu_device, hidden, heads, layers, ffn
         from bidiff import _lib
         import ctypes as C
         assert _lib.lib().bd_backbone_mega_supported(C.byref(bbg.packed().desc), L) == 1
+
+
+@pytest.mark.parametrize("hidden,heads,layers,ffn,B,L", [(768, 6, 3, 3072, 88, 128), (1152, 9, 3, 4608, 60, 128),
+                                                        (1024, 8, 3, 4096, 24, 512)])
+def test_deferred_layernorm_forward_against_layernorm_kernels(gpu_device, hidden, heads, layers, ffn, B, L):
+    """defer_layernorm = True runs LayerNorm deferred across the residual projections of large models; the default keeps
+    a LayerNorm kernel in front of every projection. Same logits within the bf16 noise of either (they are not
+    bit-equal: the rows are rounded before, not after, the normalisation), ragged key masks included."""
+    from bidiff import _lib
+    cfg = dict(RI.SMALL_CFG, hidden_size=hidden, num_heads=heads, num_layers=layers, ffn_hidden_size=ffn,
+               max_position_embeddings=max(256, L), dropout=0.0)
+    torch.manual_seed(3)
+    bb = DiffusionBackbone(**cfg).eval()
+    RI.perturb_state_dict(bb.state_dict(), 9)
+    bb = bb.to(gpu_device)
+    M = B * L
+    lib = _lib.lib()
+    assert lib.bd_gemm_deferred_ln_supported(M, hidden, hidden) == 1 and lib.bd_gemm_deferred_ln_supported(M, hidden, ffn) == 1
+    ids, attn, t = RI.backbone_inputs(cfg, 4, B=B, L=L)
+    ti, ta, tt = (torch.from_numpy(x).to(gpu_device) for x in (ids, attn, t))
+    with torch.no_grad():
+        b = bb(ti, tt, ta).float()
+        bb.defer_layernorm = True
+        a = bb(ti, tt, ta).float()
+        bb.defer_layernorm = False
+        b2 = bb(ti, tt, ta).float()
+        bb.defer_layernorm = True
+        a2 = bb(ti, tt, ta).float()
+    assert torch.isfinite(a).all() and torch.equal(a, a2) and torch.equal(b, b2)
+    assert not torch.equal(a, b)                       # the deferred path did run
+    assert float((a - b).abs().max() / b.abs().max()) < BF16_TOL / 2
 
 
 def test_stress_backbone_at_full_depth_matches_oracle(gpu_device):
