@@ -50,10 +50,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
   const int L = cu ? cu[blockIdx.z + 1] - cu[blockIdx.z] : Ls;
   if ((int)blockIdx.x * (64 * QB) >= L) return;            // no query of this sequence in the block (uniform)
   const size_t tb = cu ? (size_t)cu[blockIdx.z] : (size_t)blockIdx.z * Ls;   // first row of the sequence
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KT * ROWB + KT];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KT * ROWB + 16];
   unsigned char* const Ks = smem;
   unsigned char* const Vs = smem + KT * ROWB;
-  unsigned char* const Ms = smem + 2 * KT * ROWB;
+  unsigned long long* const Mb = (unsigned long long*)(smem + 2 * KT * ROWB);   // visible keys of the tile, one bit each
 
   constexpr int KS = DH / 32;   // k-steps of the first product
   constexpr int DT = DH / 16;   // output d-tiles of the second product
@@ -66,9 +66,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
   const int d = H * DH;
   const size_t row3 = (size_t)3 * d;
   const int q0 = blockIdx.x * (64 * QB) + wave * (16 * QB);   // block qb: queries q0 + 16 qb + c
-  // scores and running maxima are kept times log2(e): one multiply per score and the hardware's 2^x, instead of a
-  // multiply by the scale and exp(x) = 2^(x log2 e) with its own multiply; the log-sum-exp goes out in natural units
+  // exponents are taken base 2: exp(scale * (s - m)) = 2^(scale2 * s - scale2 * m), one fused multiply-add and the
+  // hardware's 2^x per score; the running maximum m stays in raw score units, the log-sum-exp goes out in natural units
   const float scale2 = scale * 1.44269504089f;
+  const f32x4 scale4 = {scale2, scale2, scale2, scale2};
 
   // Q fragments: lane holds Q[q0 + 16 qb + c][32 ks + 8 g .. +7]
   bf16x8 qf[QB][KS];
@@ -124,15 +125,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
                      ::"s"(lds_v + piece * 1024), "v"(voff), "s"(vbase) : "memory", "m0");
       }
     }
-    if (tid < KT) Ms[tid] = mv;
+    if (tid < KT) {                                   // waves 0 and 1: keys 0-63 and 64-127 of the tile
+      const unsigned long long bits = __ballot(mv != 0);
+      if (lane == 0) Mb[wave] = bits;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    const unsigned long long vis0 = Mb[0], vis1 = Mb[1];
+    const bool all_vis = (vis0 & vis1) == ~0ull;       // the common case: no masked key in the tile, no selects below
     bool live[4];
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const u32x4 m0 = *(const u32x4*)(Ms + 32 * s4), m1 = *(const u32x4*)(Ms + 32 * s4 + 16);
-      live[s4] = ((m0[0] | m0[1] | m0[2] | m0[3] | m1[0] | m1[1] | m1[2] | m1[3]) != 0u);
-    }
+    live[0] = (unsigned)vis0 != 0u; live[1] = (unsigned)(vis0 >> 32) != 0u;
+    live[2] = (unsigned)vis1 != 0u; live[3] = (unsigned)(vis1 >> 32) != 0u;
 
     // ---- S^T tiles: s[qb][tile][r] <-> key_local = 32 (tile>>1) + 8 g + 4 (tile&1) + r, query c of block qb
     f32x4 s[QB][8];
@@ -155,43 +158,47 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
     bf16x8 pf[QB][4];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-      // ---- masked online softmax along keys (lane-local + the 4 lanes sharing c)
-      float mloc = -INFINITY;
+      // ---- masked online softmax along keys (lane-local + the 4 lanes sharing c). The running maximum is kept in raw
+      //      score units; 2^(s * scale2 - m * scale2) is one fused multiply-add and one 2^x per score
+      if (!all_vis) {
 #pragma unroll
-      for (int tile = 0; tile < 8; ++tile) {
-        const int kb = 32 * (tile >> 1) + 8 * g + 4 * (tile & 1);
-        const unsigned int m4 = *(const unsigned int*)(Ms + kb);
+        for (int tile = 0; tile < 8; ++tile) {
+          const int kb = 32 * (tile >> 1) + 8 * g + 4 * (tile & 1);       // bits kb .. kb + 3 of the tile's 128
+          const unsigned m4 = (unsigned)((tile < 4 ? vis0 : vis1) >> (kb & 63)) & 0xfu;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool vis = ((m4 >> (8 * r)) & 0xffu) != 0u;
-          const float v = vis ? s[qb][tile][r] * scale2 : -INFINITY;      // base-2 logarithm domain
-          s[qb][tile][r] = v;
-          mloc = fmaxf(mloc, v);
+          for (int r = 0; r < 4; ++r)
+            if (!((m4 >> r) & 1u)) s[qb][tile][r] = -INFINITY;
         }
       }
+      float mloc = -INFINITY;
+#pragma unroll
+      for (int tile = 0; tile < 8; ++tile)
+        mloc = fmaxf(fmaxf(mloc, fmaxf(s[qb][tile][0], s[qb][tile][1])), fmaxf(s[qb][tile][2], s[qb][tile][3]));
       mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
       mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
       const float m_new = fmaxf(m_run[qb], mloc);
-      const bool dead = (m_new == -INFINITY);
-      const float m_use = dead ? 0.f : m_new;
-      const float alpha = (m_run[qb] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run[qb] - m_use);
-      float psum = 0.f;
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;           // no visible key so far: every weight 2^(-inf) = 0
+      const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_use) * scale2);    // m_run = -inf: 0
+      const float msc = m_use * scale2;
+      const f32x4 msc4 = {msc, msc, msc, msc};
+      f32x4 ps4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int tile = 0; tile < 8; ++tile)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(s[qb][tile][r] - m_use);  // 2^(-inf) = 0 for masked keys
-          s[qb][tile][r] = pv;
-          psum += pv;
-        }
+      for (int tile = 0; tile < 8; ++tile) {
+        const f32x4 e = s[qb][tile] * scale4 - msc4;                    // -inf stays -inf (scale2 > 0)
+        f32x4 pv;
+        pv[0] = __builtin_amdgcn_exp2f(e[0]); pv[1] = __builtin_amdgcn_exp2f(e[1]);
+        pv[2] = __builtin_amdgcn_exp2f(e[2]); pv[3] = __builtin_amdgcn_exp2f(e[3]);
+        s[qb][tile] = pv;
+        ps4 += pv;
+      }
+      float psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
       psum += __shfl_xor(psum, 16, 64);
       psum += __shfl_xor(psum, 32, 64);
       l_run[qb] = l_run[qb] * alpha + psum;
       m_run[qb] = m_new;
+      const f32x4 al4 = {alpha, alpha, alpha, alpha};
 #pragma unroll
-      for (int i = 0; i < DT; ++i) {
-        o[qb][i][0] *= alpha; o[qb][i][1] *= alpha; o[qb][i][2] *= alpha; o[qb][i][3] *= alpha;
-      }
+      for (int i = 0; i < DT; ++i) o[qb][i] *= al4;
 
       // ---- dropout of the probabilities (the normaliser l_run keeps every visible key)
       if (DROP) {
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
         *(u32x2*)(op + 16 * dt) = w;
       }
       if (lse_out != nullptr && g == 0)
-        lse_out[((size_t)b * H + h) * Ls + qrow] = l_run[qb] > 0.f ? (m_run[qb] * 0.69314718056f + __logf(l_run[qb])) : -INFINITY;
+        lse_out[((size_t)b * H + h) * Ls + qrow] = l_run[qb] > 0.f ? (m_run[qb] * scale + __logf(l_run[qb])) : -INFINITY;
     }
   }
 }
