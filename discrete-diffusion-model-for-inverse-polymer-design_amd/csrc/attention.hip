@@ -24,6 +24,7 @@ namespace {
 
 constexpr int KT = 128;        // keys per LDS tile
 constexpr int ROWB = 256;      // LDS row stride in bytes (also for DH < 128)
+constexpr int MAX_L = 8192;    // longest sequence of the forward kernel (its key-mask bits sit in LDS)
 
 __device__ __forceinline__ int kv_off(int row, int ch) {
   return ROWB * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
@@ -44,16 +45,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
                                                           unsigned short* __restrict__ out,
                                                           float* __restrict__ lse_out,
                                                           int Ls, int H, float scale, bd_drop_args drop,
-                                                          const int* __restrict__ cu) {
+                                                          const int* __restrict__ cu, int n_qblk) {
   // Ls = row stride of the [B, Ls] key mask, of the [B, H, Ls] log-sum-exp and of the dropout rows. With cu
   // (packed rows: sequence b occupies rows cu[b] .. cu[b + 1] - 1 of qkv / out) L is that sequence's own length.
-  const int L = cu ? cu[blockIdx.z + 1] - cu[blockIdx.z] : Ls;
-  if ((int)blockIdx.x * (64 * QB) >= L) return;            // no query of this sequence in the block (uniform)
-  const size_t tb = cu ? (size_t)cu[blockIdx.z] : (size_t)blockIdx.z * Ls;   // first row of the sequence
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KT * ROWB + 16];
+  // Workgroups are handed to the 8 XCDs in turn (blockIdx.x % 8): the logical blocks are dealt so that each XCD works
+  // through one contiguous eighth of the list, query block fastest, and the query blocks of one (sequence, head)
+  // find its K / V rows in their XCD's L2 instead of fetching them once per XCD.
+  int bz, by, bx;
+  {
+    const int n_all = gridDim.x, xcd = blockIdx.x & 7, q = n_all >> 3, rr = n_all & 7;
+    const int lin = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (blockIdx.x >> 3);
+    bx = lin % n_qblk;
+    const int t = lin / n_qblk;
+    by = t % H;
+    bz = t / H;
+  }
+  const int L = cu ? cu[bz + 1] - cu[bz] : Ls;
+  if (bx * (64 * QB) >= L) return;                         // no query of this sequence in the block (uniform)
+  const size_t tb = cu ? (size_t)cu[bz] : (size_t)bz * Ls;   // first row of the sequence
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KT * ROWB + MAX_L / 8];
   unsigned char* const Ks = smem;
   unsigned char* const Vs = smem + KT * ROWB;
-  unsigned long long* const Mb = (unsigned long long*)(smem + 2 * KT * ROWB);   // visible keys of the tile, one bit each
+  unsigned long long* const Mb = (unsigned long long*)(smem + 2 * KT * ROWB);   // visible keys of the sequence, one bit each
 
   constexpr int KS = DH / 32;   // k-steps of the first product
   constexpr int DT = DH / 16;   // output d-tiles of the second product
@@ -62,10 +75,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, c = lane & 15;
-  const int b = blockIdx.z, h = blockIdx.y;
+  const int b = bz, h = by;
   const int d = H * DH;
   const size_t row3 = (size_t)3 * d;
-  const int q0 = blockIdx.x * (64 * QB) + wave * (16 * QB);   // block qb: queries q0 + 16 qb + c
+  const int q0 = bx * (64 * QB) + wave * (16 * QB);   // block qb: queries q0 + 16 qb + c
   // exponents are taken base 2: exp(scale * (s - m)) = 2^(scale2 * s - scale2 * m), one fused multiply-add and the
   // hardware's 2^x per score; the running maximum m stays in raw score units, the log-sum-exp goes out in natural units
   const float scale2 = scale * 1.44269504089f;
@@ -90,48 +103,52 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
     for (int i = 0; i < DT; ++i) o[qb][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
-  for (int kt0 = 0; kt0 < L; kt0 += KT) {
-    if (kt0 > 0) __syncthreads();
-    // ---- stage the key mask tile and K, V of the tile's keys; the mask load and the K / V pieces are in flight
-    //      together (one memory latency, one barrier)
-    unsigned char mv = 0;
-    if (tid < KT) {
-      const int key = kt0 + tid;
-      if (key < L) mv = keymask ? (keymask[(size_t)b * Ls + key] != 0) : 1;
-    }
-    // K and V rows go to LDS by LDS-DMA, 16 pieces per wave all in flight at once: a 1-KiB piece is 4 rows x 256 B,
-    // lane i lands at row i / 16, slot i % 16 and fetches the chunk that the swizzle keeps there. (Through registers,
-    // a thread's loads and LDS stores alternate and every piece waits out a memory latency of its own: 16 latencies
-    // per tile, which was most of this kernel's time at L = 128.) Rows past the end of the sequence read its last
-    // row instead of zeros: their keys are masked, P = 0 exactly, and 0 times a finite row is 0; pieces that lie
-    // wholly past the end are not fetched, and their 32-key group is not multiplied (no visible key). Chunks a row
-    // does not have (DH < 128) land in slots nobody reads.
-    {
-      const unsigned char* kbase = (const unsigned char*)(qkv + tb * row3 + (size_t)h * DH + d);
-      const unsigned char* vbase = kbase + (size_t)d * 2;
-      const unsigned lds_k = (unsigned)(size_t)(attn_lds*)Ks, lds_v = (unsigned)(size_t)(attn_lds*)Vs;
+  // K and V rows go to LDS by LDS-DMA, 8 + 8 pieces per wave and tile: a 1-KiB piece is 4 rows x 256 B, lane i lands at
+  // row i / 16, slot i % 16 and fetches the chunk that the swizzle keeps there. Rows past the end of the sequence read
+  // its last row instead of zeros: their keys are masked, P = 0 exactly, and 0 times a finite row is 0; pieces that lie
+  // wholly past the end are not fetched, and their 32-key group is not multiplied (no visible key). Chunks a row does
+  // not have (DH < 128) land in slots nobody reads. A wave's eight pieces of a tile are one 32-key group: all fetched
+  // or none.
+  const unsigned char* const kbase = (const unsigned char*)(qkv + tb * row3 + (size_t)h * DH + d);
+  const unsigned char* const vbase = kbase + (size_t)d * 2;
+  const unsigned lds_k = (unsigned)(size_t)(attn_lds*)Ks, lds_v = (unsigned)(size_t)(attn_lds*)Vs;
+  auto stage = [&](int kt0, const unsigned char* base, unsigned lds) {
+    if (kt0 + 32 * wave >= L) return;                    // the wave's group lies past the end
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int piece = 8 * wave + j;                    // rows 4 piece .. 4 piece + 3: inside one 32-key group
-        if (kt0 + 32 * (piece >> 3) >= L) continue;        // the whole group lies past the end
-        const int row = 4 * piece + (lane >> 4);
-        int ch = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
-        ch = ch < CPR ? ch : CPR - 1;
-        const int key = min(kt0 + row, L - 1);
-        const unsigned voff = (unsigned)(((size_t)key * row3 + ch * 8) * 2);
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                     ::"s"(lds_k + piece * 1024), "v"(voff), "s"(kbase) : "memory", "m0");
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                     ::"s"(lds_v + piece * 1024), "v"(voff), "s"(vbase) : "memory", "m0");
-      }
+    for (int j = 0; j < 8; ++j) {
+      const int piece = 8 * wave + j;                    // rows 4 piece .. 4 piece + 3
+      const int row = 4 * piece + (lane >> 4);
+      int ch = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+      ch = ch < CPR ? ch : CPR - 1;
+      const int key = min(kt0 + row, L - 1);
+      const unsigned voff = (unsigned)(((size_t)key * row3 + ch * 8) * 2);
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                   ::"s"(lds + piece * 1024), "v"(voff), "s"(base) : "memory", "m0");
     }
-    if (tid < KT) {                                   // waves 0 and 1: keys 0-63 and 64-127 of the tile
-      const unsigned long long bits = __ballot(mv != 0);
-      if (lane == 0) Mb[wave] = bits;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const unsigned long long vis0 = Mb[0], vis1 = Mb[1];
+  };
+  // the visible keys of the whole sequence, one bit each (64 per wave and step), before the first piece is issued: a
+  // load the compiler waits for later would wait for every piece issued before it as well
+  for (int k0 = 64 * wave; k0 < ((L + KT - 1) / KT) * KT; k0 += 256) {      // both words of the last tile
+    const int key = k0 + lane;
+    bool vis = false;
+    if (key < L) vis = keymask ? (keymask[(size_t)b * Ls + key] != 0) : true;
+    const unsigned long long bits = __ballot(vis);
+    if (lane == 0) Mb[k0 >> 6] = bits;
+  }
+  // Per tile: K lands -> barrier -> S = K Q^T, softmax -> V lands -> barrier (nobody reads K any more: the next tile's
+  // K is fetched behind PV) -> O += V^T P^T -> barrier (nobody reads V any more: the next tile's V is fetched behind
+  // the next tile's scores). K pieces are issued before the V pieces of the same tile, so "at most the 8 V pieces
+  // outstanding" means K has landed.
+  // (the Q fragments pass through here so that their loads are waited for now, not behind the first pieces)
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[qb][ks]));
+  stage(0, kbase, lds_k);
+  stage(0, vbase, lds_v);
+  for (int kt0 = 0; kt0 < L; kt0 += KT) {
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const unsigned long long vis0 = Mb[kt0 >> 6], vis1 = Mb[(kt0 >> 6) + 1];
     const bool all_vis = (vis0 & vis1) == ~0ull;       // the common case: no masked key in the tile, no selects below
     bool live[4];
     live[0] = (unsigned)vis0 != 0u; live[1] = (unsigned)(vis0 >> 32) != 0u;
@@ -229,6 +246,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
       }
     }
 
+    // ---- V has landed, and no wave reads K any more: the next tile's K rows go out
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (kt0 + KT < L) stage(kt0 + KT, kbase, lds_k);
+
     // ---- O^T += V^T P^T ; V^T fragment via two transposing reads of 4 keys x 16 d
     const int q4 = c >> 2, p4 = c & 3;
 #pragma unroll
@@ -246,6 +267,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
         for (int qb = 0; qb < QB; ++qb)
           o[qb][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pf[qb][s4], o[qb][dt], 0, 0, 0);
       }
+    }
+    if (kt0 + KT < L) {                                  // no wave reads V any more: the next tile's V rows go out
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      stage(kt0 + KT, vbase, lds_v);
     }
   }
 
@@ -279,13 +304,14 @@ static void launch_attn_fwd(hipStream_t s, const void* qkv, const unsigned char*
   const unsigned short* q = (const unsigned short*)qkv;
   unsigned short* o = (unsigned short*)out;
   if (L > 64) {      // two query blocks per wave: 128 queries per workgroup
-    dim3 grid((L + 127) / 128, H, B);
-    if (da.thr != 0u) hipLaunchKernelGGL((attn_fwd_kernel<DH, true, 2>), grid, dim3(256), 0, s, q, keymask, o, lse, L, H, scale, da, cu);
-    else hipLaunchKernelGGL((attn_fwd_kernel<DH, false, 2>), grid, dim3(256), 0, s, q, keymask, o, lse, L, H, scale, da, cu);
+    const int nq = (L + 127) / 128;
+    dim3 grid((unsigned)((long long)nq * H * B));
+    if (da.thr != 0u) hipLaunchKernelGGL((attn_fwd_kernel<DH, true, 2>), grid, dim3(256), 0, s, q, keymask, o, lse, L, H, scale, da, cu, nq);
+    else hipLaunchKernelGGL((attn_fwd_kernel<DH, false, 2>), grid, dim3(256), 0, s, q, keymask, o, lse, L, H, scale, da, cu, nq);
   } else {
-    dim3 grid((L + 63) / 64, H, B);
-    if (da.thr != 0u) hipLaunchKernelGGL((attn_fwd_kernel<DH, true, 1>), grid, dim3(256), 0, s, q, keymask, o, lse, L, H, scale, da, cu);
-    else hipLaunchKernelGGL((attn_fwd_kernel<DH, false, 1>), grid, dim3(256), 0, s, q, keymask, o, lse, L, H, scale, da, cu);
+    dim3 grid((unsigned)((long long)H * B));
+    if (da.thr != 0u) hipLaunchKernelGGL((attn_fwd_kernel<DH, true, 1>), grid, dim3(256), 0, s, q, keymask, o, lse, L, H, scale, da, cu, 1);
+    else hipLaunchKernelGGL((attn_fwd_kernel<DH, false, 1>), grid, dim3(256), 0, s, q, keymask, o, lse, L, H, scale, da, cu, 1);
   }
 }
 
@@ -294,6 +320,8 @@ static int attention_fwd_impl(const void* qkv, const unsigned char* keymask, voi
   BD_REQUIRE(qkv && out, "bd_attention_fwd: null operand");
   BD_REQUIRE(B > 0 && L > 0 && H > 0, "bd_attention_fwd: empty shape");
   BD_REQUIRE(B <= 65535 && H <= 65535, "bd_attention_fwd: B and H must be <= 65535");
+  BD_REQUIRE(L <= MAX_L, "bd_attention_fwd: L=%d exceeds %d", L, MAX_L);
+  BD_REQUIRE((long long)B * H * ((L + 127) / 128) < (1ll << 31), "bd_attention_fwd: too many workgroups");
   bd_drop_args da;
   BD_REQUIRE(bd_drop_make(drop, site, &da), "bd_attention_fwd: dropout p=%g outside [0, 1)", (double)drop->p);
   BD_REQUIRE(da.thr == 0u || (long long)B * H * L < (1ll << 32), "bd_attention_fwd: dropout needs B*H*L < 2^32");
