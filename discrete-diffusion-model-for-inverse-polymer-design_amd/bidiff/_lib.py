@@ -123,6 +123,11 @@ SIGNATURES = {
     "bd_attention_f32": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "bd_gemm_bf16": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "bd_gemm_bf16_aux": (C.c_int, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
+    "bd_backbone_forward_rows_unfused_supported": (C.c_int, [C.POINTER(BackboneDesc), C.c_int, C.c_int]),
+    "bd_backbone_rows_workspace_bytes": (C.c_longlong, [C.POINTER(BackboneDesc), C.c_int, C.c_int]),
+    "bd_backbone_forward_rows_unfused": (C.c_int, [C.POINTER(BackboneDesc), VP, VP, VP, C.c_int, C.c_int, VP, C.c_int, VP,
+                                                   C.c_longlong, VP, C.c_longlong, VP, VP]),
+    "bd_gemm_bf16_tile256": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "bd_gemm_deferred_ln_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "bd_gemm_resid_stats_part_bytes": (C.c_longlong, [C.c_int, C.c_int]),
     "bd_gemm_bf16_resid_stats": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_float, VP]),

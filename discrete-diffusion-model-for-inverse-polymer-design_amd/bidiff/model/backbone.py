@@ -530,6 +530,19 @@ class DiffusionBackbone(nn.Module):
             return False
         return _lib.lib().bd_backbone_forward_rows_supported(C.byref(self.packed().desc), int(L)) == 1
 
+    def rows_forward_mode(self, B, L):
+        """Which chosen-row forward this model has for a [B, L] batch: "single_launch" (``need_all`` handled on the
+        device), "per_layer" (large models on the per-layer kernels: the caller runs the full forward for a step that
+        flagged a sequence in ``need_all``), or None."""
+        if self.compute_dtype != "bf16":
+            return None
+        desc = C.byref(self.packed().desc)
+        if _lib.lib().bd_backbone_forward_rows_supported(desc, int(L)) == 1:
+            return "single_launch"
+        if _lib.lib().bd_backbone_forward_rows_unfused_supported(desc, int(B), int(L)) == 1:
+            return "per_layer"
+        return None
+
     def run_forward_rows(self, input_ids, timesteps, keymask, row_pos, need_all, row_cap, hidden_out, wave_table=None):
         """The inference forward for a reverse step that reads few rows: ``hidden_out`` [B, L, d] bf16 receives the
         final-norm rows at positions ``row_pos`` [B * row_cap] (int32, -1 = none) and every row of the sequences
@@ -545,6 +558,20 @@ class DiffusionBackbone(nn.Module):
         if row_pos.dtype != torch.int32 or row_pos.numel() != B * row_cap or need_all.dtype != torch.uint8 \
                 or need_all.numel() != B:
             raise ValueError("row_pos must be int32 [B * row_cap] and need_all uint8 [B]")
+        if _lib.lib().bd_backbone_forward_rows_supported(C.byref(pk.desc), L) != 1:
+            # per-layer kernels: chosen rows only behind the last layer's attention (no need_all list: see rows_forward_mode)
+            rneed = _lib.lib().bd_backbone_rows_workspace_bytes(C.byref(pk.desc), B, int(row_cap))
+            if rneed < 0:
+                _lib.check(-1, "bd_backbone_rows_workspace_bytes")
+            rws = self.__dict__.get("_rows_ws")
+            if rws is None or rws.numel() < rneed or rws.device != ids.device:
+                rws = torch.empty(rneed, dtype=torch.uint8, device=ids.device)
+                self.__dict__["_rows_ws"] = rws
+            rc = _lib.lib().bd_backbone_forward_rows_unfused(
+                C.byref(pk.desc), _lib.ptr(ids), _lib.ptr(timesteps), _lib.ptr(keymask), B, L, _lib.ptr(row_pos),
+                int(row_cap), _lib.ptr(ws), need, _lib.ptr(rws), rneed, _lib.ptr(hidden_out), _lib.stream_handle())
+            _lib.check(rc, "bd_backbone_forward_rows_unfused")
+            return hidden_out
         n_blocks = 0
         if wave_table is not None:
             if wave_table.dtype != torch.int32 or wave_table.dim() != 2 or wave_table.shape[1] != 4 \

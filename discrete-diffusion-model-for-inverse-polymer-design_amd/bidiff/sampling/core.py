@@ -200,8 +200,11 @@ class ReverseSampler:
 
         use_rows = self.row_workspace if self.row_workspace is not None else tt.V > 128
         use_rows = bool(use_rows) and d in (128, 256, 384, 512)
-        choose_first = (bool(self.choose_first) and getattr(backbone, "compute_dtype", "bf16") == "bf16"
-                        and hasattr(backbone, "run_forward_rows") and backbone.rows_forward_supported(L))
+        rows_mode = None
+        if bool(self.choose_first) and getattr(backbone, "compute_dtype", "bf16") == "bf16" \
+                and hasattr(backbone, "rows_forward_mode"):
+            rows_mode = backbone.rows_forward_mode(B, L)
+        choose_first = rows_mode is not None
         if use_rows or choose_first:
             # A sequence that starts with n masks draws about n / T of them per step (k = max(1, int(n_t / t)) keeps
             # n_t near n t / T), at most ceil(L / T): the row list covers that many rows per sequence, rounded up to
@@ -246,7 +249,12 @@ class ReverseSampler:
                 if choose_first:
                     _lib.check(lib.bd_sample_choose_rows(C.byref(a), row_pos.data_ptr(), need_all.data_ptr(), row_cap,
                                                          stream), "bd_sample_choose_rows")
-                    backbone.run_forward_rows(ids, ts, keymask, row_pos, need_all, row_cap, hidden, wave_table=wave_table)
+                    if rows_mode == "per_layer" and bool(need_all.any().item()):
+                        # a draw beyond the row list (rare): this step computes every hidden row. The read-back waits
+                        # for the device, which costs nothing beside these models' forward of tens of milliseconds
+                        backbone.run_forward(ids, ts, keymask, want_hidden=True, want_logits=False, hidden_out=hidden)
+                    else:
+                        backbone.run_forward_rows(ids, ts, keymask, row_pos, need_all, row_cap, hidden, wave_table=wave_table)
                 else:
                     backbone.run_forward(ids, ts, keymask, want_hidden=True, want_logits=False, hidden_out=hidden,
                                          **({} if wave_table is None else {"wave_table": wave_table}))

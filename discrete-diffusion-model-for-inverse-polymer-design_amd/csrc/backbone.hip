@@ -218,6 +218,118 @@ extern "C" int bd_backbone_forward_ragged(const bd_backbone_desc* desc, const lo
   return BD_OK;
 }
 
+// ---- the forward of a reverse step that reads few rows, for models on the per-layer kernels ---------------------
+namespace {
+// slot s = (sequence s / cap, position row_pos[s]); empty slots (-1) take the sequence's first row and are not written back
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ x, const unsigned short* __restrict__ att,
+                                                          const int* __restrict__ row_pos, float* __restrict__ xc,
+                                                          unsigned short* __restrict__ attc, int L, int cap, int d, int aw) {
+  const int s = blockIdx.x;
+  const int pos = row_pos[s];
+  const size_t row = (size_t)(s / cap) * L + (pos < 0 ? 0 : pos);
+  for (int i = threadIdx.x; i < d / 4; i += 256) ((f32x4*)(xc + (size_t)s * d))[i] = ((const f32x4*)(x + row * d))[i];
+  for (int i = threadIdx.x; i < aw / 8; i += 256) ((u32x4*)(attc + (size_t)s * aw))[i] = ((const u32x4*)(att + row * aw))[i];
+}
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const unsigned short* __restrict__ hc, const int* __restrict__ row_pos,
+                                                           unsigned short* __restrict__ hidden, int L, int cap, int d) {
+  const int s = blockIdx.x;
+  const int pos = row_pos[s];
+  if (pos < 0) return;
+  const size_t row = (size_t)(s / cap) * L + pos;
+  for (int i = threadIdx.x; i < d / 8; i += 256) ((u32x4*)(hidden + row * d))[i] = ((const u32x4*)(hc + (size_t)s * d))[i];
+}
+
+struct RowsCarve { long long xc, attc, hc, ffc, hfc, total; };
+RowsCarve rows_carve(const bd_backbone_desc& c, long long Mc) {
+  RowsCarve w;
+  long long off = 0;
+  const long long aw = c.attn_width > 0 ? c.attn_width : c.d;
+  w.xc = off;   off += align256(Mc * c.d * 4);
+  w.attc = off; off += align256(Mc * aw * 2);
+  w.hc = off;   off += align256(Mc * c.d * 2);
+  w.ffc = off;  off += align256(Mc * c.ffn * 2);
+  w.hfc = off;  off += align256(Mc * c.d * 2);
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+// 1 when the model runs on the per-layer kernels with all four projections of a block on the eight-wave GEMM at
+// B * L rows (the chosen rows' products then run on the same kernel and come out bit for bit as in the full forward)
+extern "C" int bd_backbone_forward_rows_unfused_supported(const bd_backbone_desc* desc, int B, int L) {
+  if (check_desc(desc) != BD_OK || B <= 0 || L <= 0 || L > desc->max_pos || desc->n_layers < 1) return 0;
+  const bd_backbone_desc& c = *desc;
+  const long long M = (long long)B * L;
+  if (M >= (1ll << 31)) return 0;
+  const int d = c.d, F = c.ffn, aw = c.attn_width > 0 ? c.attn_width : d, Mi = (int)M;
+  if (bd_backbone_mega_supported(desc, L)) return 0;
+  if (bd_ffn_fused_supported(d, F) || (bd_attn_block_supported(d, c.n_heads, L) && aw == bd_attn_block_width(d, c.n_heads))) return 0;
+  if (bd_gemm_panel_supported(3 * aw, d, 1) || bd_gemm_panel_supported(F, d, 1)) return 0;
+  for (int i = 0; i < c.n_layers; ++i)
+    if (c.layers[i].cs_qkv_ln || c.layers[i].cs_fc1_ln) return 0;      // deferred LayerNorm: other roundings in the full forward
+  return bd_gemm_deferred_ln_supported(Mi, d, aw) && bd_gemm_deferred_ln_supported(Mi, d, F) &&
+         bd_gemm_deferred_ln_supported(Mi, 3 * aw, d) && bd_gemm_deferred_ln_supported(Mi, F, d);
+}
+
+extern "C" long long bd_backbone_rows_workspace_bytes(const bd_backbone_desc* desc, int B, int row_cap) {
+  if (check_desc(desc) != BD_OK || B <= 0 || row_cap < 1 || row_cap > 32) return -1;
+  return rows_carve(*desc, (long long)B * row_cap).total;
+}
+
+extern "C" int bd_backbone_forward_rows_unfused(const bd_backbone_desc* desc, const long long* ids,
+                                                const long long* timesteps, const unsigned char* keymask, int B, int L,
+                                                const int* row_pos, int row_cap, void* workspace, long long workspace_bytes,
+                                                void* rows_workspace, long long rows_workspace_bytes, void* hidden_out,
+                                                void* stream) {
+  if (desc == nullptr) return bd_fail(BD_ERR_ARG, "backbone: null descriptor");
+  BD_REQUIRE(row_pos && rows_workspace && hidden_out, "bd_backbone_forward_rows_unfused: null operand");
+  BD_REQUIRE(row_cap >= 1 && row_cap <= 32, "bd_backbone_forward_rows_unfused: row_cap=%d outside 1..32", row_cap);
+  BD_REQUIRE(bd_backbone_forward_rows_unfused_supported(desc, B, L),
+             "bd_backbone_forward_rows_unfused: model shape or batch %d x %d not on the per-layer large-tile kernels", B, L);
+  const bd_backbone_desc& c = *desc;
+  const long long Mc = (long long)B * row_cap;
+  const RowsCarve rw = rows_carve(c, Mc);
+  BD_REQUIRE(rows_workspace_bytes >= rw.total, "bd_backbone_forward_rows_unfused: rows workspace %lld < %lld bytes",
+             rows_workspace_bytes, rw.total);
+  BD_REQUIRE(((size_t)rows_workspace & 255) == 0, "bd_backbone_forward_rows_unfused: rows workspace must be 256-byte aligned");
+  // every layer but the last for every row (the residual rows stay in the workspace)
+  int rc = forward_impl(desc, ids, timesteps, keymask, B, L, workspace, workspace_bytes, c.n_layers - 1, nullptr, nullptr,
+                        nullptr, stream);
+  if (rc) return rc;
+  const long long M = (long long)B * L;
+  const Carve w = carve(c, M);
+  char* ws = (char*)workspace;
+  float* x = (float*)(ws + w.x);
+  void* h = ws + w.h;
+  void* qkv = ws + w.qkv;
+  void* att = ws + w.att;
+  const int d = c.d, F = c.ffn, Mi = (int)M, Mci = (int)Mc;
+  const int aw = c.attn_width > 0 ? c.attn_width : d;
+  const bd_layer_weights& lw = c.layers[c.n_layers - 1];
+  // the last layer: attention needs every row's keys and values; behind it only the chosen rows go on
+  if ((rc = bd_layernorm(x, lw.ln1_g, lw.ln1_b, h, nullptr, nullptr, Mi, d, c.ln_eps, stream))) return rc;
+  if ((rc = bd_gemm_bf16(h, lw.w_qkv, lw.b_qkv, qkv, Mi, 3 * aw, 3 * aw, d, 3 * aw, 0, stream))) return rc;
+  if ((rc = bd_attention_fwd(qkv, keymask, att, nullptr, B, L, c.n_heads, aw / c.n_heads, stream))) return rc;
+  char* rs = (char*)rows_workspace;
+  float* xc = (float*)(rs + rw.xc);
+  void* attc = rs + rw.attc;
+  void* hc = rs + rw.hc;
+  void* ffc = rs + rw.ffc;
+  void* hfc = rs + rw.hfc;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)Mc), dim3(256), 0, s, x, (const unsigned short*)att, row_pos, xc,
+                     (unsigned short*)attc, L, row_cap, d, aw);
+  if ((rc = bd_check_launch("bd_backbone_forward_rows_unfused (gather)"))) return rc;
+  if ((rc = bd_gemm_bf16_tile256(attc, lw.w_o, lw.b_o, xc, Mci, d, aw, 2, stream))) return rc;
+  if ((rc = bd_layernorm(xc, lw.ln2_g, lw.ln2_b, hc, nullptr, nullptr, Mci, d, c.ln_eps, stream))) return rc;
+  if ((rc = bd_gemm_bf16_tile256(hc, lw.w_fc1, lw.b_fc1, ffc, Mci, F, d, 1, stream))) return rc;
+  if ((rc = bd_gemm_bf16_tile256(ffc, lw.w_fc2, lw.b_fc2, xc, Mci, d, F, 2, stream))) return rc;
+  if ((rc = bd_layernorm(xc, c.lnf_g, c.lnf_b, hfc, nullptr, nullptr, Mci, d, c.ln_eps, stream))) return rc;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)Mc), dim3(256), 0, s, (const unsigned short*)hfc, row_pos,
+                     (unsigned short*)hidden_out, L, row_cap, d);
+  return bd_check_launch("bd_backbone_forward_rows_unfused (scatter)");
+}
+
 extern "C" int bd_backbone_forward_layers(const bd_backbone_desc* desc, const long long* ids,
                                           const long long* timesteps, const unsigned char* keymask, int B,
                                           int L, void* workspace, long long workspace_bytes, int n_run,

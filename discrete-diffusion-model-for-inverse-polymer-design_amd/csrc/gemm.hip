@@ -1110,6 +1110,24 @@ extern "C" int bd_gemm_bf16_deferred_ln(const void* xb, const void* W_ln, const 
                                    : launch8p<EPI_BIAS_GELU_BF16>(a, s, "bd_gemm_bf16_deferred_ln");
 }
 
+// The eight-wave kernel whatever the tile count: a few rows of a product whose full form runs on that kernel come out
+// bit for bit as there (an element's sum does not depend on the tile it sits in). Epilogues 0, 1, 2.
+extern "C" int bd_gemm_bf16_tile256(const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                                    int epilogue, void* stream) {
+  BD_REQUIRE(A && W && out, "bd_gemm_bf16_tile256: null operand");
+  BD_REQUIRE(epilogue >= 0 && epilogue <= 2, "bd_gemm_bf16_tile256: epilogue %d (0, 1 or 2)", epilogue);
+  BD_REQUIRE(deferred_shape_ok(M, N, K), "bd_gemm_bf16_tile256: M=%d N=%d K=%d (N a multiple of 128, K of 64, K >= 128)", M, N, K);
+  GemmArgs a{};
+  a.A = (const unsigned short*)A; a.W = (const unsigned short*)W; a.bias = bias; a.out = out;
+  a.M = M; a.Npad = N; a.n_real = N; a.K = K; a.ldc = N;
+  hipStream_t s = (hipStream_t)stream;
+  switch (epilogue) {
+    case EPI_BIAS_BF16: return launch8p<EPI_BIAS_BF16>(a, s, "bd_gemm_bf16_tile256");
+    case EPI_BIAS_GELU_BF16: return launch8p<EPI_BIAS_GELU_BF16>(a, s, "bd_gemm_bf16_tile256");
+    default: return launch8p<EPI_BIAS_RESID_F32>(a, s, "bd_gemm_bf16_tile256");
+  }
+}
+
 // Batched C_b = A_b W_b^T over `batch` problems of one shape (element strides sA, sW, sOut; a zero
 // stride shares the operand), bf16 out with row stride N. aux == null: out = acc. aux given (bf16,
 // laid out like out): out = rn(rn(beta * aux) + rn(alpha * rn(acc))).

@@ -715,6 +715,28 @@ int bd_prof_read(long long* launches, double* total_ms, double* total_flops, int
  * repairs; -1 = all families together. */
 int bd_prof_read_kind(int kind, long long* launches, double* total_ms, double* total_flops, int reset);
 
+/* The chosen-row forward for models on the per-layer kernels (d >= 512 or L > 128: no single-launch forward). Every
+ * layer but the last runs for every row; in the last layer attention still needs every row's keys and values, and
+ * behind it only the rows in row_pos [B * row_cap] (int32 positions, -1 = empty slot; bd_sample_choose_rows writes
+ * them) go through the output projection, the feed-forward block and the final LayerNorm, as B * row_cap gathered
+ * rows. hidden_out [B*L, d] bf16 receives those rows, its other rows keep what they held. The rows written equal
+ * bd_backbone_forward's bit for bit: bd_backbone_forward_rows_unfused_supported answers 1 only where the full forward
+ * runs all four projections of a block on the eight-wave GEMM at B * L rows without fused or panel kernels and
+ * without the deferred LayerNorm (cs_*_ln null), and the gathered rows' products run on that same kernel
+ * (bd_gemm_bf16_tile256: the eight-wave kernel whatever the tile count; epilogues 0, 1, 2 of bd_gemm_bf16, N a
+ * multiple of 128, K a multiple of 64, K >= 128). There is no need_all list here: a caller whose step flagged a
+ * sequence (bd_sample_choose_rows) runs bd_backbone_forward for that step. rows_workspace: scratch of
+ * bd_backbone_rows_workspace_bytes(desc, B, row_cap) bytes, 256-byte aligned, beside the forward's own workspace.
+ * Replaces the same call sites as bd_backbone_forward_rows (src/sampling/sampler.py:654-700). */
+int bd_backbone_forward_rows_unfused_supported(const bd_backbone_desc* desc, int B, int L);
+long long bd_backbone_rows_workspace_bytes(const bd_backbone_desc* desc, int B, int row_cap);
+int bd_backbone_forward_rows_unfused(const bd_backbone_desc* desc, const long long* ids, const long long* timesteps,
+                                     const unsigned char* keymask, int B, int L, const int* row_pos, int row_cap,
+                                     void* workspace, long long workspace_bytes, void* rows_workspace,
+                                     long long rows_workspace_bytes, void* hidden_out, void* stream);
+int bd_gemm_bf16_tile256(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int epilogue,
+                         void* stream);
+
 /* Clock diagnostics of the single-launch forward (bd_backbone_mega and the entry points that use it): while a
  * buffer is set, workgroup b < n_workgroups of every such launch writes four 64-bit words to stamps[4 b ..]:
  * the shader-clock counter and the 100 MHz real-time counter when it starts, and both again when it ends. The

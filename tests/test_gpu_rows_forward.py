@@ -191,3 +191,66 @@ def test_rows_forward_argument_errors(gpu_device):
     # L beyond the single-launch forward: not supported, the reverse loop then keeps the full forward
     assert not bb.rows_forward_supported(200)
     assert bb.rows_forward_supported(128)
+
+
+# ---------------------------------------------------------------- large models on the per-layer kernels
+@pytest.mark.parametrize("d,heads,F,B,L,cap,ragged", [(768, 6, 3072, 88, 128, 2, False), (1024, 8, 4096, 24, 512, 8, True)])
+def test_per_layer_chosen_rows_equal_the_full_forward(gpu_device, d, heads, F, B, L, cap, ragged):
+    """Models without the single-launch forward (the reference's medium size; the stress shape with L = 512): the chosen
+    rows go through the last layer's output projection, feed-forward block and the final LayerNorm as gathered rows on
+    the same GEMM kernel as the full forward. Same bits at the listed positions, every other row untouched."""
+    dev = gpu_device
+    T = 12
+    _, tok = H.make_sampler("smiles")
+    model = build_model(tok, dev, T, heads=heads, layers=2, d=d, F=F)
+    smp, _ = H.make_sampler("smiles", model=model, num_steps=T, device=str(dev))
+    bb = model.backbone
+    assert bb.rows_forward_mode(B, L) == "per_layer"
+    assert bb.rows_forward_mode(2, L) is None          # too few rows for the large-tile kernels: full forward
+    rng = np.random.RandomState(d + L)
+    lens = rng.randint(L // 4, L + 1, size=B) if ragged else None
+    ids_np, attn_np = _partially_masked(tok, B, L, rng, frac=[0.05, 0.3, 0.6, 1.0], lengths=lens)
+    ids = torch.from_numpy(ids_np).to(dev)
+    keymask = torch.from_numpy((attn_np != 0).astype(np.uint8)).to(dev)
+    fixed = (ids != tok.mask_token_id).to(torch.uint8)
+    t = 5
+    row_pos, need_all, _ = _choose(smp, ids, fixed, t, T, cap)
+    rp = row_pos.cpu().numpy()
+    assert (rp >= 0).sum() > B // 2 and (rp < 0).sum() > 0
+    ts = torch.full((B,), t, device=dev, dtype=torch.long)
+    full = torch.zeros(B, L, d, dtype=torch.bfloat16, device=dev)
+    bb.run_forward(ids, ts, keymask, want_hidden=True, hidden_out=full)
+    sentinel = 0x7FC1
+    got = torch.full((B, L, d), sentinel, dtype=torch.int16, device=dev).view(torch.bfloat16)
+    bb.run_forward_rows(ids, ts, keymask, row_pos.reshape(-1), need_all, cap, got)
+    torch.cuda.synchronize()
+    g, f = got.view(torch.int16).cpu().numpy(), full.view(torch.int16).cpu().numpy()
+    listed = np.zeros((B, L), dtype=bool)
+    for b in range(B):
+        for r in rp[b]:
+            if r >= 0:
+                listed[b, r] = True
+    np.testing.assert_array_equal(g[listed], f[listed])
+    assert (g[~listed] == np.int16(sentinel)).all()
+    # the deferred LayerNorm rounds differently in the full forward: the shortcut steps aside
+    bb.defer_layernorm = True
+    assert bb.rows_forward_mode(B, L) is None
+    bb.defer_layernorm = False
+
+
+def test_per_layer_sampler_draws_the_same_ids_with_rows_chosen_first(gpu_device):
+    """A whole reverse loop on a medium-size model (per-layer kernels), the shortcut on and off; T < L / 16 makes some
+    steps draw more rows than the list holds, which sends those steps through the full forward."""
+    dev = gpu_device
+    T, B, L = 6, 88, 128
+    _, tok = H.make_sampler("smiles")
+    model = build_model(tok, dev, T, heads=6, layers=2, d=768, F=3072)
+    outs = []
+    for first in (True, False):
+        smp, _ = H.make_sampler("smiles", model=model, num_steps=T, temperature=0.9, device=str(dev))
+        smp._core.seed = 5
+        smp._core.choose_first = first
+        ids, strings = smp.sample(B, L, show_progress=False, seq_offset=2)
+        outs.append((ids.cpu(), strings))
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+    assert (outs[0][0] != tok.mask_token_id).all()
