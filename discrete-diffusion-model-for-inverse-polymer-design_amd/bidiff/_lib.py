@@ -45,6 +45,11 @@ class LayerWeights(C.Structure):
     ]
 
 
+class WgradJob(C.Structure):
+    _fields_ = [("dY", VP), ("X", VP), ("dW", VP * 3), ("db", VP * 3),
+                ("ldy", C.c_int), ("ldx", C.c_int), ("n_seg", C.c_int), ("seg_rows", C.c_int), ("K", C.c_int)]
+
+
 class BackboneDesc(C.Structure):
     _fields_ = [
         ("d", C.c_int), ("n_layers", C.c_int), ("n_heads", C.c_int), ("ffn", C.c_int),
@@ -140,6 +145,7 @@ SIGNATURES = {
     "bd_layernorm_parts_finish": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP]),
     "bd_decode_ids": (C.c_int, [VP, C.c_int, C.c_int, VP, VP, C.c_int, VP, VP, C.c_int, VP]),
     "bd_gemm_wgrad_bf16": (C.c_int, [VP, C.c_int, VP, C.c_int, VP, C.c_int, C.c_int, C.c_int, VP]),
+    "bd_gemm_wgrad_group": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP]),
     "bd_gemm_wgrad_segments": (C.c_int, [VP, C.c_int, VP, C.c_int, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]),
     "bd_gemm_bf16_batched": (C.c_int, [VP, VP, VP, VP, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong, C.c_int, C.c_int,
                                        C.c_int, C.c_float, C.c_float, VP]),

@@ -160,6 +160,25 @@ def _wgrad(dY, X, dW, M, N, K, db=None):
                                           _s()), "bd_gemm_wgrad_segments")
 
 
+def _wgrad_group(jobs):
+    """The weight-gradient products of one hand-over ((dY, X, dW, M, N, K, db) each, as for ``_wgrad``) in one launch:
+    every output tile owned by one workgroup (bd_gemm_wgrad_group)."""
+    arr = (_lib.WgradJob * len(jobs))()
+    M = jobs[0][3]
+    for j, (dY, X, dW, M_, N, K, db) in zip(arr, jobs):
+        if M_ != M:
+            raise ValueError("weight-gradient jobs of one launch share their token range")
+        dws = dW if isinstance(dW, (list, tuple)) else [dW]
+        dbs = db if isinstance(db, (list, tuple)) else ([db] if db is not None else [])
+        j.dY, j.X = dY.data_ptr(), X.data_ptr()
+        for k, t in enumerate(dws):
+            j.dW[k] = t.data_ptr()
+        for k, t in enumerate(dbs):
+            j.db[k] = t.data_ptr()
+        j.ldy, j.ldx, j.n_seg, j.seg_rows, j.K = dY.stride(0), X.stride(0), len(dws), N // len(dws), K
+    _ck(_lib.lib().bd_gemm_wgrad_group(arr, len(jobs), M, -1, _s()), "bd_gemm_wgrad_group")
+
+
 def _colsum(dY, out, M, N):
     _ck(_lib.lib().bd_colsum_bf16(_lib.ptr(dY), dY.stride(0), _lib.ptr(out), M, N, _s()), "bd_colsum_bf16")
 
@@ -557,8 +576,7 @@ class _BackboneFn(torch.autograd.Function):
             side.wait_event(ready)
             _STREAM[0] = side_h              # the launch helpers take their stream from here
             try:
-                for job in pending:
-                    _wgrad(*job)
+                _wgrad_group([tuple(job[:6]) + ((job[6] if len(job) > 6 else None),) for job in pending])
             finally:
                 _STREAM[0] = main_h
             pending.clear()

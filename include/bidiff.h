@@ -411,6 +411,22 @@ int bd_layernorm_bwd_parts(const void* dy_bf16, const float* x, const float* sta
                            void* dx_bf16, const bd_dropout* drop, unsigned site, void* stream);
 int bd_layernorm_parts_finish(const bd_ln_parts_job* jobs, int n_jobs, int n_parts, int d, void* stream);
 
+/* Several weight-gradient products of one token range handed over together (a layer's four: the stacked q | k | v
+ * projection, the output projection and the two feed-forward layers). Default: one bd_gemm_wgrad_segments launch per
+ * job (token range split over the chip, fp32 atomics). With single_owner = 1 (-1: BD_WGRAD_GROUP in the environment,
+ * default 0) and M % 32 == 0:
+ * ONE launch for up to four jobs in which every 128 x 128 output tile is owned by one workgroup that walks all M
+ * tokens, so the sums do not depend on the order in which workgroups finish (one writer per element: the same bits on
+ * every run); measured 15 % slower per training step, hence opt-in. Each job is a bd_gemm_wgrad_segments call's
+ * arguments (db entries may be null). Replaces the weight half of loss.backward() like bd_gemm_wgrad_segments
+ * (src/training/trainer_backbone.py:437-441). */
+typedef struct bd_wgrad_job {
+  const void* dY; const void* X;      /* bf16 [M, ldy], [M, ldx] */
+  float* dW[3]; float* db[3];         /* fp32 destinations of the n_seg row segments, accumulated into */
+  int ldy, ldx, n_seg, seg_rows, K;
+} bd_wgrad_job;
+int bd_gemm_wgrad_group(const bd_wgrad_job* jobs, int n_jobs, int M, int single_owner, void* stream);
+
 /* dW[N,K] += dY[M,N]^T * X[M,K] (bf16 in, fp32 accumulate with atomics); N, K multiples of 128.
  * (autograd of nn.Linear weights, src/model/backbone.py:25-28,91-92,195). */
 int bd_gemm_wgrad_bf16(const void* dY, int ldy, const void* X, int ldx, float* dW, int M, int N, int K,

@@ -157,6 +157,50 @@ def test_wgrad_exact_integers(gpu_device, M):
     assert torch.equal(dW.cpu(), dY.t() @ X)
 
 
+@pytest.mark.parametrize("single_owner", [0, 1])
+def test_wgrad_group_of_a_layers_products(gpu_device, single_owner):
+    """bd_gemm_wgrad_group on a layer's four products (the stacked q | k | v one in three segments with bias sums),
+    split launches (0) and the single-owner launch (1): exact on small integers, accumulating into the destinations;
+    the single-owner launch gives the same bits on random data twice in a row."""
+    dev = gpu_device
+    M, d, F = 1184, 256, 512
+    g = torch.Generator().manual_seed(3)
+    shapes = [(3 * d, d, 3), (d, d, 1), (F, d, 1), (d, F, 1)]          # (N, K, segments)
+
+    def run(make):
+        jobs = (_lib.WgradJob * len(shapes))()
+        keep, refs = [], []
+        for j, (N, K, nseg) in zip(jobs, shapes):
+            dY, X = make(M, N), make(M, K)
+            a, b = dY.to(dev).bfloat16(), X.to(dev).bfloat16()
+            seg = N // nseg
+            dW = [torch.ones(seg, K, device=dev) for _ in range(nseg)]
+            db = [torch.zeros(seg, device=dev) for _ in range(nseg)]
+            keep += [a, b] + dW + db
+            j.dY, j.X = a.data_ptr(), b.data_ptr()
+            for k in range(nseg):
+                j.dW[k], j.db[k] = dW[k].data_ptr(), db[k].data_ptr()
+            j.ldy, j.ldx, j.n_seg, j.seg_rows, j.K = N, K, nseg, seg, K
+            refs.append((a.float().cpu(), b.float().cpu(), dW, db, seg))
+        _lib.check(_lib.lib().bd_gemm_wgrad_group(jobs, len(shapes), M, single_owner, _s()), "wgrad group")
+        torch.cuda.synchronize()
+        return refs
+
+    for a, b, dW, db, seg in run(lambda m, n: torch.randint(-3, 4, (m, n), generator=g).float()):
+        want = a.t() @ b + 1.0
+        for k, (w, bsum) in enumerate(zip(dW, db)):
+            assert torch.equal(w.cpu(), want[k * seg:(k + 1) * seg])
+            assert torch.equal(bsum.cpu(), a[:, k * seg:(k + 1) * seg].sum(0))
+    if single_owner:
+        g.manual_seed(9)
+        first = [[w.clone() for w in dW] for _, _, dW, _, _ in run(lambda m, n: torch.randn(m, n, generator=g))]
+        g.manual_seed(9)
+        again = [[w.clone() for w in dW] for _, _, dW, _, _ in run(lambda m, n: torch.randn(m, n, generator=g))]
+        for x, y in zip(first, again):
+            for u, v in zip(x, y):
+                assert torch.equal(u, v)
+
+
 def test_dgelu_epilogue_and_preactivation_save(gpu_device):
     dev = gpu_device
     M, N, K = 300, 256, 128
