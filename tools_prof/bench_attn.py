@@ -3,6 +3,7 @@ import os, sys, torch
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(_ROOT, 'discrete-diffusion-model-for-inverse-polymer-design_amd')); sys.path.insert(0, _ROOT)
 from bidiff import _lib
+if os.environ.get('BD_LIB_PATH'): _lib.LIB_PATH = os.environ['BD_LIB_PATH']      # A/B against another build
 dev = torch.device('cuda:0'); lib = _lib.lib(); s = _lib.stream_handle()
 for (B, H, L, dh) in ((128, 8, 512, 128), (2048, 6, 128, 128), (2048, 9, 128, 128), (256, 8, 512, 64), (2048, 8, 128, 64)):
     qkv = torch.randn(B * L, 3 * H * dh, device=dev).bfloat16()
