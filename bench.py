@@ -35,7 +35,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 peak of MI355X
 HBM_PEAK_GBPS = 8000.0
 
 # kernel families of the library's event profiler (bd_prof_read_kind): name, unit of the work figure
-KINDS = {0: ("gemm_bf16_kernel (tiled GEMM: vocabulary head, projections, data gradients)", "flop"),
+KINDS = {0: ("gemm_bf16_kernel (tiled GEMM family, gemm8p_kernel on large shapes: vocabulary head, projections, data gradients)", "flop"),
          1: ("gemm_panel_kernel (row-panel projection with fused LayerNorm)", "flop"),
          2: ("ffn_fused_kernel (LayerNorm + fc1 + GELU + fc2 + residual)", "flop"),
          3: ("attn_block_kernel (LayerNorm + QKV + attention + out-proj + residual)", "flop"),
