@@ -600,8 +600,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, T == 4 ?
 // -------------------------------------------------------------------------------------------------
 // The same 256 x 256 tile with EIGHT waves, two per SIMD, that take turns (ping-pong): waves 0-3 hold the tile's upper
 // 128 activation rows, waves 4-7 the lower 128 (a wave = 128 rows x 64 columns: 8 x 4 accumulators of
-// v_mfma_f32_16x16x32_bf16, 128 registers), and the second group runs one barrier behind the first, so that on every
-// SIMD one wave issues its 16 MFMAs of a phase while its partner reads operands from LDS and sends LDS-DMA pieces off.
+// v_mfma_f32_16x16x32_bf16, 128 registers), and through a tile's K-loop the second group runs one barrier behind the
+// first, so that on every SIMD one wave issues its 16 MFMAs of a phase while its partner reads operands from LDS and
+// sends LDS-DMA pieces off. The kernel is persistent: a workgroup walks several output tiles (see the tile list in the
+// kernel), and the stage stream below runs on from a tile's last K-tiles into the next tile's first ones.
 // A K-tile (64 k-values) is four phases, one per 64 x 32 quadrant of the wave's output:
 //   P1 reads X0 (2 weight tiles) + Y0 (4 activation tiles), P2 reads X1, P3 reads Y1, P4 reads nothing
 //   (quadrants (Y0,X0), (Y0,X1), (Y1,X1), (Y1,X0); every fragment is read from LDS once per K-tile).
@@ -611,10 +613,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, T == 4 ?
 //   tile u: P1 -> weights' upper half of tile u + 1, P2 -> activation rows 64-127 (of both halves) of u + 1,
 //           P3 -> activation rows 0-63 of u + 2, P4 -> weights' lower half of u + 2,
 // i.e. every stage is issued 4 to 6 phases before its first read, and 3 to 4 stages are in flight at any time. A wave
-// waits for its own pieces only (vmcnt(6) in P4 for what P1 of the next tile reads, vmcnt(8) in P2 for what P3 reads,
-// each with exactly that many younger pieces behind it: past the last K-tile the stages are still issued, re-reading
-// the last tile's bytes into regions nobody reads, so that the counts hold to the end), and every read of a region comes
-// behind a barrier that all waves pass after that wait. Weight rows are permuted inside the 64-row sub-tiles so that a
+// waits for its own pieces only (vmcnt(6) in P4 for what P1 of the next K-tile reads, vmcnt(8) in P2 for what P3 reads,
+// each with exactly that many younger pieces behind it: past the workgroup's last tile the stages are still issued,
+// re-reading that tile's first bytes into regions nobody reads, so that the counts hold to the end), and every read of
+// a region comes behind a barrier that all waves pass after that wait. Weight rows are permuted inside the 64-row sub-tiles so that a
 // lane's 16 accumulators of an activation row are 16 consecutive output columns (epilogue_row as in the kernels above).
 constexpr int G8_BUF = 65536;
 
