@@ -826,60 +826,96 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs p) {
             cs[4 * j4 + 0] = t[0]; cs[4 * j4 + 1] = t[1]; cs[4 * j4 + 2] = t[2]; cs[4 * j4 + 3] = t[3];
           }
         }
+        // The residual epilogue reads the rows it updates: the loads of four row groups go out together ahead of their
+        // uses (one memory latency per four groups; one group at a time, the eight latencies in a row were most of a
+        // tile's output time). Rows past M load the last row instead (no branch around the loads) and are dropped below.
 #pragma unroll
-        for (int tm = 0; tm < 8; ++tm) {
-          const int m = cur.m0 + 128 * wr + 16 * tm + c;
-          if (m >= p.M) continue;
-          float v[16];
-          if (ln_in) {
-            // A held the raw rows x (bf16), the weights carry gamma: LN(x) W^T = rstd (x W^T - mean colsum(W))
-            const float mean = p.ln_stats[2 * (size_t)m], rstd = p.ln_stats[2 * (size_t)m + 1];
+        for (int half = 0; half < 2; ++half) {
+          f32x4 res[4][4];
+          if (EPI == EPI_BIAS_RESID_F32) {
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
+            for (int t = 0; t < 4; ++t) {
+              const int m = cur.m0 + 128 * wr + 16 * (4 * half + t) + c;
+              const float* ri = (p.aux_in ? (const float*)p.aux_in : (const float*)p.out) + (size_t)(m < p.M ? m : p.M - 1) * p.ldc + nb;
 #pragma unroll
-              for (int j = 0; j < 4; ++j)
-                v[4 * tn + j] = rstd * (acc[tm][tn][j] - mean * cs[4 * tn + j]) + bv[4 * tn + j];
-          } else {
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-              for (int j = 0; j < 4; ++j) v[4 * tn + j] = acc[tm][tn][j] + bv[4 * tn + j];
+              for (int j4 = 0; j4 < 4; ++j4) res[t][j4] = *(const f32x4*)(ri + 4 * j4);
+            }
           }
-          if (ln_out) {
-            // the updated residual row segment in fp32, its bf16 copy (the next projection's operand) and its share of
-            // the row's LayerNorm sums: the four lanes of a row (g = 0 .. 3) hold the wave's 64 columns of it
-            float* o = (float*)p.out + (size_t)m * p.ldc + nb;
-            const float* ri = p.aux_in ? (const float*)p.aux_in + (size_t)m * p.ldc + nb : o;
-            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int j4 = 0; j4 < 4; ++j4) {
-              f32x4 x = *(const f32x4*)(ri + 4 * j4);
+          for (int t = 0; t < 4; ++t) {
+            const int tm = 4 * half + t;
+            const int m = cur.m0 + 128 * wr + 16 * tm + c;
+            if (m >= p.M) continue;
+            float v[16];
+            if (ln_in) {
+              // A held the raw rows x (bf16), the weights carry gamma: LN(x) W^T = rstd (x W^T - mean colsum(W))
+              const float mean = p.ln_stats[2 * (size_t)m], rstd = p.ln_stats[2 * (size_t)m + 1];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                x[e] += v[4 * j4 + e];
-                v[4 * j4 + e] = x[e];
-                s1 += x[e];
-                s2 += x[e] * x[e];
+              for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                  v[4 * tn + j] = rstd * (acc[tm][tn][j] - mean * cs[4 * tn + j]) + bv[4 * tn + j];
+            } else {
+#pragma unroll
+              for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[4 * tn + j] = acc[tm][tn][j] + bv[4 * tn + j];
+            }
+            if (EPI == EPI_BIAS_RESID_F32) {
+              // the updated residual row segment in fp32; with ln_out also its bf16 copy (the next projection's operand)
+              // and its share of the row's LayerNorm sums: the four lanes of a row (g = 0 .. 3) hold the wave's 64 columns
+              if (DROP) {
+                float f[16];
+                drop_factors16(p.drop, m, nb, f);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] *= f[j];
               }
-              *(f32x4*)(o + 4 * j4) = x;
+              float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+              for (int j4 = 0; j4 < 4; ++j4) {
+                f32x4 x = res[t][j4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  x[e] += v[4 * j4 + e];
+                  v[4 * j4 + e] = x[e];
+                  s1 += x[e];
+                  s2 += x[e] * x[e];
+                }
+                res[t][j4] = x;           // stored below, behind the last use of the four groups' loads
+              }
+              if (ln_out) {
+                unsigned short* ob = p.xb_out + (size_t)m * p.ldc + nb;
+                u32x4 lo, hi;
+                lo[0] = bd_pack_bf16x2(v[0], v[1]);   lo[1] = bd_pack_bf16x2(v[2], v[3]);
+                lo[2] = bd_pack_bf16x2(v[4], v[5]);   lo[3] = bd_pack_bf16x2(v[6], v[7]);
+                hi[0] = bd_pack_bf16x2(v[8], v[9]);   hi[1] = bd_pack_bf16x2(v[10], v[11]);
+                hi[2] = bd_pack_bf16x2(v[12], v[13]); hi[3] = bd_pack_bf16x2(v[14], v[15]);
+                *(u32x4*)(ob) = lo;
+                *(u32x4*)(ob + 8) = hi;
+                s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+                s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+                if (g == 0) {
+                  const int blk = (cur.n0 >> 6) + wc;
+                  f32x2 st; st[0] = s1; st[1] = s2;
+                  *(f32x2*)(p.part_out + ((size_t)blk * p.M + m) * 2) = st;
+                }
+              }
+            } else {
+              epilogue_row<EPI, DROP>(p, m, nb, v);
             }
-            unsigned short* ob = p.xb_out + (size_t)m * p.ldc + nb;
-            u32x4 lo, hi;
-            lo[0] = bd_pack_bf16x2(v[0], v[1]);   lo[1] = bd_pack_bf16x2(v[2], v[3]);
-            lo[2] = bd_pack_bf16x2(v[4], v[5]);   lo[3] = bd_pack_bf16x2(v[6], v[7]);
-            hi[0] = bd_pack_bf16x2(v[8], v[9]);   hi[1] = bd_pack_bf16x2(v[10], v[11]);
-            hi[2] = bd_pack_bf16x2(v[12], v[13]); hi[3] = bd_pack_bf16x2(v[14], v[15]);
-            *(u32x4*)(ob) = lo;
-            *(u32x4*)(ob + 8) = hi;
-            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-            if (g == 0) {
-              const int blk = (cur.n0 >> 6) + wc;
-              f32x2 st; st[0] = s1; st[1] = s2;
-              *(f32x2*)(p.part_out + ((size_t)blk * p.M + m) * 2) = st;
+          }
+          // Loads and stores share one counter: a store between two groups' uses would make the second group's wait for
+          // its loads a wait for that store's acknowledgement as well. All four groups' rows go out here, in one run.
+          if (EPI == EPI_BIAS_RESID_F32) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int m = cur.m0 + 128 * wr + 16 * (4 * half + t) + c;
+              if (m >= p.M) continue;
+              float* o = (float*)p.out + (size_t)m * p.ldc + nb;
+#pragma unroll
+              for (int j4 = 0; j4 < 4; ++j4) *(f32x4*)(o + 4 * j4) = res[t][j4];
             }
-          } else {
-            epilogue_row<EPI, DROP>(p, m, nb, v);
           }
         }
       }

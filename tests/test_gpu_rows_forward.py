@@ -4,6 +4,7 @@ the masked positions, no logits involved), so the last feed-forward block and th
 alone. Checked here: the row list equals the oracle's choice, the rows written equal the full forward's bit for bit,
 and the samplers return the same ids with the shortcut on and off."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -206,7 +207,8 @@ def test_per_layer_chosen_rows_equal_the_full_forward(gpu_device, d, heads, F, B
     smp, _ = H.make_sampler("smiles", model=model, num_steps=T, device=str(dev))
     bb = model.backbone
     assert bb.rows_forward_mode(B, L) == "per_layer"
-    assert bb.rows_forward_mode(2, L) is None          # too few rows for the large-tile kernels: full forward
+    if os.environ.get("BD_GEMM8P", "1") != "2":        # (2 forces the eight-wave kernel on every shape)
+        assert bb.rows_forward_mode(2, L) is None      # too few rows for the large-tile kernels: full forward
     rng = np.random.RandomState(d + L)
     lens = rng.randint(L // 4, L + 1, size=B) if ragged else None
     ids_np, attn_np = _partially_masked(tok, B, L, rng, frac=[0.05, 0.3, 0.6, 1.0], lengths=lens)
