@@ -811,11 +811,11 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs p) {
     // order: the counted waits of the K-loop stay sufficient (a store still on its way can only make them wait longer).
     if (wr == 0) __builtin_amdgcn_s_barrier();
     {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every stage piece issued so far has landed before the first store goes out
       const int nb = cur.n0 + 64 * wc + 16 * g;
+      float bv[16];
+      load_bias16<EPI>(p, nb < p.Npad ? nb : 0, bv);      // (on its way while the wait below drains the stage pieces)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every stage piece issued so far has landed before the first store goes out
       if (nb < p.Npad) {
-        float bv[16];
-        load_bias16<EPI>(p, nb, bv);
         const bool ln_in = (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16) && p.ln_stats != nullptr;
         const bool ln_out = EPI == EPI_BIAS_RESID_F32 && !DROP && p.xb_out != nullptr;
         float cs[16];
