@@ -728,8 +728,12 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs p) {
   f32x4 acc[8][4];
 
   // ---- prologue: K-tile 0 whole and the first two stages of K-tile 1; K-tile 0's first three stages landed
-  issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0); issue(0, 1); issue(1, 1);
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // K-tile 0 whole (its rows 64-127 too: see P2 below)
+  // A tile begins with its K-tile 0 whole and K-tile 1 but for the activation rows 64-127 landed (here: one drain; for the
+  // tiles that follow: the drain in front of the previous tile's stores), so that its first K-tile and a half run
+  // without a counted wait: such a wait would also wait for the previous tile's stores, which are slow to be
+  // acknowledged when every CU writes its tile at once.
+  issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0); issue(0, 1); issue(1, 1); issue(2, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
 #define G8_RDX(dst, tn, kk, base)                                                                                  \
@@ -755,7 +759,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs p) {
       for (int kk = 0; kk < 2; ++kk) {
         G8_RDY(Y[0][kk], 0, kk, yb); G8_RDY(Y[1][kk], 1, kk, yb); G8_RDY(Y[2][kk], 2, kk, yb); G8_RDY(Y[3][kk], 3, kk, yb);
       }
-      issue(2, u + 1);
+      if (u > 0) issue(2, u + 1);                          // (K-tile 1's came with the previous tile's last phase)
       __builtin_amdgcn_s_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)"
                    : "+v"(X0[0][0]), "+v"(X0[0][1]), "+v"(X0[1][0]), "+v"(X0[1][1]), "+v"(Y[0][0]), "+v"(Y[0][1]), "+v"(Y[1][0]),
@@ -770,9 +774,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs p) {
         G8_RDX(X1[0][kk], 2, kk, xb); G8_RDX(X1[1][kk], 3, kk, xb);
       }
       issue(3, u + 1);
-      // own pieces of rows 64-127 of THIS K-tile (read in P3) landed. A tile's first K-tile is whole before the tile
-      // begins (prologue; wait in front of the previous tile's stores), and a counted wait here would also wait for
-      // those stores, which are younger than the pieces in question and slow when every CU writes its tile at once
+      // own pieces of rows 64-127 of THIS K-tile (read in P3) landed; K-tile 0's were there before the tile began
       if (u > 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(X1[0][0]), "+v"(X1[0][1]), "+v"(X1[1][0]), "+v"(X1[1][1]));
@@ -796,7 +798,14 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs p) {
       __builtin_amdgcn_s_barrier();
       // ---- P4: quadrant (Y1, X0); what P1 of the next K-tile reads has landed when this wait returns
       issue(1, u + 2);
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      if (u == nt - 1) {
+        // the tile's last K-tile: the weights' upper half of the NEXT tile's K-tile 1 goes out as well (its region was
+        // last read two phases ago), and the wait leaves that stage in flight too
+        issue(2, u + 2);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else if (u > 0) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      }
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_s_setprio(1);
       g8_quadrant<1, 0>(acc, X0, Y);
