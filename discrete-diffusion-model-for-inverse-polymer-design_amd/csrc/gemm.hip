@@ -612,7 +612,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, T == 4 ?
 // region by region as soon as no wave reads the region any more, one 16-KB stage per phase (2 pieces per thread):
 //   tile u: P1 -> weights' upper half of tile u + 1, P2 -> activation rows 64-127 (of both halves) of u + 1,
 //           P3 -> activation rows 0-63 of u + 2, P4 -> weights' lower half of u + 2,
-// i.e. every stage is issued 4 to 6 phases before its first read, and 3 to 4 stages are in flight at any time. A wave
+// (a tile's first phase issues nothing and its last phase two stages: the next tile begins with a K-tile and a half
+// landed, see the prologue), i.e. every stage is issued 4 to 6 phases before its first read, and 3 to 4 stages are in
+// flight at any time. A wave
 // waits for its own pieces only (vmcnt(6) in P4 for what P1 of the next K-tile reads, vmcnt(8) in P2 for what P3 reads,
 // each with exactly that many younger pieces behind it: past the workgroup's last tile the stages are still issued,
 // re-reading that tile's first bytes into regions nobody reads, so that the counts hold to the end), and every read of
