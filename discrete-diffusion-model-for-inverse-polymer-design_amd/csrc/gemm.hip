@@ -843,6 +843,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs p) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
           f32x4 res[4][4];
+          f32x2 sums[4];
           if (EPI == EPI_BIAS_RESID_F32) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -895,21 +896,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs p) {
                 res[t][j4] = x;           // stored below, behind the last use of the four groups' loads
               }
               if (ln_out) {
-                unsigned short* ob = p.xb_out + (size_t)m * p.ldc + nb;
-                u32x4 lo, hi;
-                lo[0] = bd_pack_bf16x2(v[0], v[1]);   lo[1] = bd_pack_bf16x2(v[2], v[3]);
-                lo[2] = bd_pack_bf16x2(v[4], v[5]);   lo[3] = bd_pack_bf16x2(v[6], v[7]);
-                hi[0] = bd_pack_bf16x2(v[8], v[9]);   hi[1] = bd_pack_bf16x2(v[10], v[11]);
-                hi[2] = bd_pack_bf16x2(v[12], v[13]); hi[3] = bd_pack_bf16x2(v[14], v[15]);
-                *(u32x4*)(ob) = lo;
-                *(u32x4*)(ob + 8) = hi;
                 s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
                 s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-                if (g == 0) {
-                  const int blk = (cur.n0 >> 6) + wc;
-                  f32x2 st; st[0] = s1; st[1] = s2;
-                  *(f32x2*)(p.part_out + ((size_t)blk * p.M + m) * 2) = st;
-                }
+                sums[t][0] = s1; sums[t][1] = s2;
               }
             } else {
               epilogue_row<EPI, DROP>(p, m, nb, v);
@@ -926,6 +915,17 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs p) {
               float* o = (float*)p.out + (size_t)m * p.ldc + nb;
 #pragma unroll
               for (int j4 = 0; j4 < 4; ++j4) *(f32x4*)(o + 4 * j4) = res[t][j4];
+              if (ln_out) {
+                unsigned short* ob = p.xb_out + (size_t)m * p.ldc + nb;
+                u32x4 lo, hi;
+                lo[0] = bd_pack_bf16x2(res[t][0][0], res[t][0][1]); lo[1] = bd_pack_bf16x2(res[t][0][2], res[t][0][3]);
+                lo[2] = bd_pack_bf16x2(res[t][1][0], res[t][1][1]); lo[3] = bd_pack_bf16x2(res[t][1][2], res[t][1][3]);
+                hi[0] = bd_pack_bf16x2(res[t][2][0], res[t][2][1]); hi[1] = bd_pack_bf16x2(res[t][2][2], res[t][2][3]);
+                hi[2] = bd_pack_bf16x2(res[t][3][0], res[t][3][1]); hi[3] = bd_pack_bf16x2(res[t][3][2], res[t][3][3]);
+                *(u32x4*)(ob) = lo;
+                *(u32x4*)(ob + 8) = hi;
+                if (g == 0) *(f32x2*)(p.part_out + ((size_t)((cur.n0 >> 6) + wc) * p.M + m) * 2) = sums[t];
+              }
             }
           }
         }

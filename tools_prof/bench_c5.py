@@ -15,6 +15,8 @@ T = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 L = 512
 torch.manual_seed(42)
 bb = DiffusionBackbone(tok.vocab_size, 1024, 24, H, 4096, 512, 100, 0.1, tok.pad_token_id)
+import os
+bb.defer_layernorm = os.environ.get('BD_DEFER') == '1'      # A/B of the deferred LayerNorm
 model = DiscreteMaskingDiffusion(bb, num_steps=100, mask_token_id=tok.mask_token_id, pad_token_id=tok.pad_token_id,
                                  bos_token_id=tok.bos_token_id, eos_token_id=tok.eos_token_id).to(dev).eval()
 ids = torch.randint(5, tok.vocab_size, (B, L), device=dev)
