@@ -830,11 +830,17 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs p) {
         const bool ln_in = (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16) && p.ln_stats != nullptr;
         const bool ln_out = EPI == EPI_BIAS_RESID_F32 && !DROP && p.xb_out != nullptr;
         float cs[16];
+        f32x2 rowst[8];       // (mean, 1 / std) of the lane's eight rows, all requested at once
         if (ln_in) {
 #pragma unroll
           for (int j4 = 0; j4 < 4; ++j4) {
             const f32x4 t = *(const f32x4*)(p.ln_colsum + nb + 4 * j4);
             cs[4 * j4 + 0] = t[0]; cs[4 * j4 + 1] = t[1]; cs[4 * j4 + 2] = t[2]; cs[4 * j4 + 3] = t[3];
+          }
+#pragma unroll
+          for (int tm = 0; tm < 8; ++tm) {
+            const int m = cur.m0 + 128 * wr + 16 * tm + c;
+            rowst[tm] = *(const f32x2*)(p.ln_stats + 2 * (size_t)(m < p.M ? m : p.M - 1));
           }
         }
         // The residual epilogue reads the rows it updates: the loads of four row groups go out together ahead of their
@@ -861,7 +867,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs p) {
             float v[16];
             if (ln_in) {
               // A held the raw rows x (bf16), the weights carry gamma: LN(x) W^T = rstd (x W^T - mean colsum(W))
-              const float mean = p.ln_stats[2 * (size_t)m], rstd = p.ln_stats[2 * (size_t)m + 1];
+              const float mean = rowst[tm][0], rstd = rowst[tm][1];
 #pragma unroll
               for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
