@@ -256,3 +256,38 @@ def test_per_layer_sampler_draws_the_same_ids_with_rows_chosen_first(gpu_device)
         outs.append((ids.cpu(), strings))
     assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
     assert (outs[0][0] != tok.mask_token_id).all()
+
+
+def test_per_layer_rows_forward_argument_errors(gpu_device):
+    dev = gpu_device
+    _, tok = H.make_sampler("smiles")
+    model = build_model(tok, dev, 4, heads=6, layers=1, d=768, F=3072)
+    bb = model.backbone
+    B, L, cap = 88, 128, 2
+    lib = _lib.lib()
+    pk = bb.packed()
+    ws, need = bb._workspace(pk, B, L, dev)
+    rneed = lib.bd_backbone_rows_workspace_bytes(C.byref(pk.desc), B, cap)
+    assert rneed > 0 and lib.bd_backbone_rows_workspace_bytes(C.byref(pk.desc), B, 0) < 0
+    rws = torch.empty(rneed, dtype=torch.uint8, device=dev)
+    ids = torch.full((B, L), tok.mask_token_id, dtype=torch.long, device=dev)
+    ts = torch.ones(B, dtype=torch.long, device=dev)
+    rp = torch.full((B * cap,), -1, dtype=torch.int32, device=dev)
+    hid = torch.empty(B, L, 768, dtype=torch.bfloat16, device=dev)
+    st = _lib.stream_handle()
+    call = lambda b, cap_, rbytes, out: lib.bd_backbone_forward_rows_unfused(
+        C.byref(pk.desc), _lib.ptr(ids), _lib.ptr(ts), None, b, L, _lib.ptr(rp), cap_, _lib.ptr(ws), need, _lib.ptr(rws), rbytes,
+        out, st)
+    assert call(B, cap, rneed, _lib.ptr(hid)) == 0            # every slot empty: nothing written, no fault
+    assert call(B, 0, rneed, _lib.ptr(hid)) != 0 and b"row_cap" in lib.bd_last_error()
+    assert call(B, cap, 16, _lib.ptr(hid)) != 0 and b"rows workspace" in lib.bd_last_error()
+    assert call(B, cap, rneed, None) != 0
+    assert call(2, cap, rneed, _lib.ptr(hid)) != 0 and b"large-tile" in lib.bd_last_error()
+    torch.cuda.synchronize()
+    # the forced large-tile product: shape rules of the eight-wave kernel
+    a = torch.zeros(64, 256, dtype=torch.bfloat16, device=dev)
+    o = torch.zeros(64, 256, dtype=torch.bfloat16, device=dev)
+    assert lib.bd_gemm_bf16_tile256(_lib.ptr(a), _lib.ptr(a), None, _lib.ptr(o), 64, 256, 256, 0, st) == 0
+    assert lib.bd_gemm_bf16_tile256(_lib.ptr(a), _lib.ptr(a), None, _lib.ptr(o), 64, 256, 96, 0, st) != 0
+    assert lib.bd_gemm_bf16_tile256(_lib.ptr(a), _lib.ptr(a), None, _lib.ptr(o), 64, 256, 256, 3, st) != 0
+    torch.cuda.synchronize()
