@@ -1,6 +1,7 @@
-import sys, math, torch
+import os, sys, math, torch
 sys.path.insert(0, 'discrete-diffusion-model-for-inverse-polymer-design_amd'); sys.path.insert(0, '.')
 from bidiff import _lib
+if os.environ.get('BD_LIB_PATH'): _lib.LIB_PATH = os.environ['BD_LIB_PATH']      # A/B against another build
 dev = torch.device('cuda:0'); lib = _lib.lib()
 def bench(M, N, K, epi, iters=20):
     A = torch.randn(M, K, device=dev).bfloat16(); W = (torch.randn(N, K, device=dev) / math.sqrt(K)).bfloat16()

@@ -4,7 +4,7 @@
 cd $GRAFT_REPO_ROOT || exit 1
 mkdir -p gpurun_out /tmp/micro
 : > gpurun_out/micro.txt
-for f in stream_rate dma_forms lds_rate mfma_fill mfma_order mfma_dma mfma_real; do
+for f in stream_rate dma_forms lds_rate mfma_fill mfma_order mfma_dma mfma_real store_pattern; do
   echo "== $f" >> gpurun_out/micro.txt
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o /tmp/micro/$f tools_prof/micro/$f.hip 2> /dev/null || exit 1
   timeout -k 10 60 /tmp/micro/$f >> gpurun_out/micro.txt 2>&1 || exit 1
