@@ -117,6 +117,7 @@ def test_benchmark_architecture_matches_reference_golden(gpu_device, V, capsys):
     (768, 6, 2, 3072, 40, 128),    # the reference's "medium" size (config.yaml model_sizes), 5120 rows
     (768, 6, 3, 3072, 88, 128),    # medium, 11264 rows: enough tiles for the eight-wave GEMM
     (1152, 9, 2, 4608, 60, 128),   # its "large" size: widths that are odd multiples of 128, 7680 rows (eight-wave GEMM)
+    (1536, 12, 2, 6144, 48, 128),  # its "xl" size, 6144 rows (eight-wave GEMM on every projection)
 ])
 def test_other_architectures_match_oracle(gpu_device, hidden, heads, layers, ffn, B, L):
     cfg = dict(RI.SMALL_CFG, hidden_size=hidden, num_heads=heads, num_layers=layers, ffn_hidden_size=ffn,

@@ -8,7 +8,7 @@ from bidiff import _lib
 from bidiff.model.backbone import DiffusionBackbone
 dev = torch.device('cuda:0'); torch.cuda.set_device(0)
 lib = _lib.lib()
-SIZES = {"medium": (768, 12, 6, 3072), "large": (1152, 18, 9, 4608)}
+SIZES = {"medium": (768, 12, 6, 3072), "large": (1152, 18, 9, 4608), "xl": (1536, 24, 12, 6144)}
 B, L, V = int(sys.argv[1]) if len(sys.argv) > 1 else 2048, 128, 39
 for name, (d, n, h, f) in SIZES.items():
     torch.manual_seed(1)
