@@ -519,6 +519,36 @@ def c5_bench(dev, B, L, T):
             "roofline": roofline_of(table), "kernels": named(table)}
 
 
+def sizes_bench(dev, B=2048, L=128):
+    """Full denoiser forward of the reference's other model sizes (Bi_Diffusion_SMILES/configs/config.yaml model_sizes:
+    medium, large, xl) at the sampling shape B x 128: time per forward and whole-path TFLOP/s."""
+    from bidiff.model.backbone import DiffusionBackbone
+    from bidiff.utils import synthetic
+    tok = synthetic.smiles_tokenizer()
+    res = {}
+    for name, (d, n, h, f) in (("medium", (768, 12, 6, 3072)), ("large", (1152, 18, 9, 4608)), ("xl", (1536, 24, 12, 6144))):
+        torch.manual_seed(1)
+        bb = DiffusionBackbone(tok.vocab_size, d, n, h, f, 256, 100, 0.1, tok.pad_token_id).to(dev).eval()
+        ids = torch.randint(5, tok.vocab_size, (B, L), device=dev)
+        t_ = torch.full((B,), 50, device=dev, dtype=torch.long)
+        am = torch.ones(B, L, dtype=torch.long, device=dev)
+        with torch.no_grad():
+            for _ in range(2):
+                bb.get_hidden_states(ids, t_, am)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                bb.get_hidden_states(ids, t_, am)
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        tfl = fwd_flops_per_token(d, n, f, L, tok.vocab_size) * B * L / dt / 1e12
+        res[name] = {"hidden": d, "layers": n, "heads": h, "ffn": f, "batch": B, "seq_len": L, "ms_per_forward": 1e3 * dt,
+                     "whole_path_tflops": tfl, "whole_path_frac": tfl / MFMA_BF16_PEAK_TFLOPS}
+        del bb
+        torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -637,7 +667,8 @@ def main():
                          # sequences of at most 64 tokens: two per workgroup of the single-launch forward
                          ("selfies_L64", lambda: variant_bench(dev, "selfies", B, 64, T, world, rank)),
                          ("smiles_lengths_mean38", lambda: ragged_bench(dev, B, T)),
-                         ("c5_24L_d1024_L512", lambda: c5_bench(dev, args.c5_batch, 512, T))):
+                         ("c5_24L_d1024_L512", lambda: c5_bench(dev, args.c5_batch, 512, T)),
+                         ("model_sizes_forward", lambda: sizes_bench(dev))):
             torch.cuda.empty_cache()
             try:
                 configs[name] = fn()
