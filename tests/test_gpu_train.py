@@ -398,9 +398,9 @@ def test_training_forward_backward_matches_oracle_autograd(gpu_device, name):
     assert model.backbone.position_embedding.weight.grad[ids.shape[1]:].abs().max().item() == 0.0
 
 
-@pytest.mark.parametrize("hidden,heads,ffn", [(768, 6, 3072), (1152, 9, 4608)])
+@pytest.mark.parametrize("hidden,heads,ffn", [(768, 6, 3072), (1152, 9, 4608), (1536, 12, 6144)])
 def test_training_at_medium_and_large_widths_matches_oracle_autograd(gpu_device, hidden, heads, ffn):
-    """The reference's medium and large model sizes (configs/config.yaml model_sizes), two layers of each: loss and
+    """The reference's medium, large and xl model sizes (configs/config.yaml model_sizes), two layers of each: loss and
     every parameter gradient against fp32 autograd of the CPU restatement. 7168 rows, so that the products of the
     large width (1152 and 3456: odd multiples of 128) take the large-tile kernel with its half-empty last column
     tile, in the forward pass and in the data-gradient products."""
