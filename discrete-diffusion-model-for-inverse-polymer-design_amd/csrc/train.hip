@@ -548,6 +548,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradArgs p) {
   wgrad_dma_tile(p, tile, xcd + 8 * j, 8 * p.J, smem);
 }
 
+// One product, every output tile owned by ONE workgroup that walks all the token chunks (large outputs over a short
+// token range; bd_gemm_wgrad_segments chooses). Tiles are dealt so that the workgroups of an XCD (blockIdx % 8) hold
+// neighbouring tiles of the list: the same rows of dY, neighbouring columns of X.
+__global__ __launch_bounds__(256, 2) void wgrad_single_kernel(WgradArgs p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[WG_STAGES * WG_STAGE];
+  const int n_all = gridDim.x, xcd = blockIdx.x & 7, q = n_all >> 3, rr = n_all & 7;
+  const int tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (blockIdx.x >> 3);
+  wgrad_dma_tile(p, tile, 0, 1, smem);
+}
+
 // Several products in one launch, every output tile owned by ONE workgroup that walks all the token chunks: the launch
 // keeps (sum of tiles) workgroups busy for the length of the token range instead of filling the chip in bursts, which
 // is what a stream running beside the data-gradient chain should do; and with a single writer per output element the
@@ -1427,7 +1437,7 @@ extern "C" int bd_layernorm_bwd(const void* dy_bf16, const float* x, const float
 // workgroup on the CU (load latency with three steps in flight) up to 0.6 us with two; the atomic
 // epilogues of all 8 J token groups drain at the L2 rate of one fp32 add per clock and channel,
 // ~0.35 M per microsecond.
-static int wgrad_groups(int tiles, int n_chunks, long long out_elems, int cus_per_xcd) {
+static int wgrad_groups(int tiles, int n_chunks, long long out_elems, int cus_per_xcd, double* t_best = nullptr) {
   int best = 1;
   double best_t = 1e30;
   const int per_xcd = (n_chunks + 7) / 8;
@@ -1440,7 +1450,17 @@ static int wgrad_groups(int tiles, int n_chunks, long long out_elems, int cus_pe
     const double t = rounds * ((per_xcd + J - 1) / J) * step_us + 8.0 * J * (double)out_elems / 0.35e6;
     if (t < best_t) { best_t = t; best = J; }
   }
+  if (t_best) *t_best = best_t;
   return best;
+}
+// The same model for ONE workgroup per output tile that walks every token chunk (wgrad_group_kernel): no split of the
+// token range, one atomic per output element. It wins where the output is large and the token range short (the wide
+// models' projections at a few thousand rows: eight partial sums per element would drain longer than the products take).
+static double wgrad_single_owner_us(int tiles, int n_chunks, long long out_elems, int ncu) {
+  const int rounds = (tiles + 2 * ncu - 1) / (2 * ncu);
+  double w = (double)tiles / ncu / rounds;
+  w = w < 1.0 ? 1.0 : w;
+  return rounds * (double)n_chunks * (0.42 + 0.18 * (w - 1.0)) + (double)out_elems / 0.35e6;
 }
 
 extern "C" int bd_gemm_wgrad_segments(const void* dY, int ldy, const void* X, int ldx, float* const* dW,
@@ -1469,7 +1489,15 @@ extern "C" int bd_gemm_wgrad_segments(const void* dY, int ldy, const void* X, in
     a.ldy = ldy; a.ldx = ldx; a.seg_rows = seg_rows; a.N = N; a.K = K;
     a.tiles_k = K / 128; a.tiles = (N / 128) * a.tiles_k; a.n_chunks = M / 32;
     static int forced = getenv("BD_WGRAD_J") ? atoi(getenv("BD_WGRAD_J")) : 0;
-    a.J = forced > 0 ? forced : wgrad_groups(a.tiles, a.n_chunks, (long long)N * K, ncu / 8 > 0 ? ncu / 8 : 1);
+    static int single = getenv("BD_WGRAD_SINGLE") ? atoi(getenv("BD_WGRAD_SINGLE")) : -1;      // 0 never, 1 always, -1 by the model
+    double t_split = 0.0;
+    a.J = forced > 0 ? forced : wgrad_groups(a.tiles, a.n_chunks, (long long)N * K, ncu / 8 > 0 ? ncu / 8 : 1, &t_split);
+    if (single == 1 || (single < 0 && forced <= 0 && a.tiles >= ncu / 2 &&
+                        wgrad_single_owner_us(a.tiles, a.n_chunks, (long long)N * K, ncu) < t_split)) {
+      a.J = 1;
+      hipLaunchKernelGGL(wgrad_single_kernel, dim3((unsigned)a.tiles), dim3(256), 0, s, a);
+      return bd_check_launch("bd_gemm_wgrad");
+    }
     const long long grid = 8ll * a.tiles * a.J;
     BD_REQUIRE(grid < (1ll << 31), "bd_gemm_wgrad: too many tiles");
     hipLaunchKernelGGL(wgrad_dma_kernel, dim3((unsigned)grid), dim3(256), 0, s, a);
