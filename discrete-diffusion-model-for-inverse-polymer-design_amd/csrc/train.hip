@@ -1418,9 +1418,14 @@ static int layernorm_bwd_impl(const void* dy_bf16, const float* x, const float* 
     hipLaunchKernelGGL(layernorm_bwd_kernel<NV>, grid, block, lds, s, dy, x, stats, gamma, dres, dx, dgamma, dbeta, M, d, ob, \
                        da, rpw, n_parts, part_stride);                                                          \
   } while (0)
+  // NV = 16-byte pieces of a row per lane: the reference's widths 768 / 1152 / 1536 are 3 / 5 (4.5) / 6 of them, and a
+  // kernel sized for 8 keeps a third of its row registers empty and spills
   if (nv <= 1) BD_LNB(1);
   else if (nv <= 2) BD_LNB(2);
+  else if (nv <= 3) BD_LNB(3);
   else if (nv <= 4) BD_LNB(4);
+  else if (nv <= 5) BD_LNB(5);
+  else if (nv <= 6) BD_LNB(6);
   else BD_LNB(8);
 #undef BD_LNB
   return bd_check_launch("bd_layernorm_bwd");

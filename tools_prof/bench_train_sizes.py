@@ -9,6 +9,8 @@ from bidiff.training.optimizer import FlatAdamW
 import bench
 dev = torch.device("cuda:0")
 for name, (d, n, h, f, Bt) in {"medium": (768, 12, 6, 3072, 128), "large": (1152, 18, 9, 4608, 128), "xl": (1536, 24, 12, 6144, 64)}.items():
+    if os.environ.get("BD_TRAIN_SIZES_ONLY") not in (None, "", name):
+        continue
     torch.manual_seed(0)
     bb = DiffusionBackbone(803, d, n, h, f, 256, 50, 0.1, 0)
     model = DiscreteMaskingDiffusion(bb, num_steps=50, mask_token_id=1, pad_token_id=0, bos_token_id=2, eos_token_id=3).to(dev).train()
