@@ -1277,6 +1277,43 @@ __global__ __launch_bounds__(256) void multi_cast_kernel(const bd_cast_job* __re
   // destination indices of source row r / source column c (head re-blocking moves one of them)
   auto drow = [&](int r) { return j.pad_axis == 1 ? cast_job_reblock(j, r) : r; };
   auto dcol = [&](int c) { return j.pad_axis == 2 ? cast_job_reblock(j, c) : c; };
+  // Four elements per thread where the job's shape allows 16-byte reads and 8-byte stores (every weight matrix of the
+  // models: dimensions and head groups are multiples of 4); other jobs go element by element below.
+  const bool vec = !(j.transpose & 2) && (j.cols & 3) == 0 && (j.rows & 3) == 0 && (j.ld & 3) == 0 &&
+                   (j.pad_axis == 0 || ((j.group & 3) == 0 && (j.group_pad & 3) == 0)) &&
+                   (((size_t)j.src & 15) == 0) && (((size_t)j.dst & 7) == 0);
+  if (vec) {
+    const int vx = threadIdx.x & 15, vy = threadIdx.x >> 4;
+    if (!j.transpose) {
+      const int c = c0 + 4 * vx;
+      if (c < j.cols)
+        for (int i = vy; i < 64 && r0 + i < j.rows; i += 16) {
+          const f32x4 v = *(const f32x4*)(j.src + (size_t)(r0 + i) * j.cols + c);
+          u32x2 o;
+          o[0] = (unsigned)bd_f32_to_bf16(sc * v[0]) | ((unsigned)bd_f32_to_bf16(sc * v[1]) << 16);
+          o[1] = (unsigned)bd_f32_to_bf16(sc * v[2]) | ((unsigned)bd_f32_to_bf16(sc * v[3]) << 16);
+          *(u32x2*)(dst + (size_t)drow(r0 + i) * j.ld + dcol(c)) = o;
+        }
+      return;
+    }
+    for (int i = vy; i < 64; i += 16) {
+      const int c = c0 + 4 * vx;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r0 + i < j.rows && c < j.cols) v = *(const f32x4*)(j.src + (size_t)(r0 + i) * j.cols + c);
+      tile[i][4 * vx + 0] = sc * v[0]; tile[i][4 * vx + 1] = sc * v[1];
+      tile[i][4 * vx + 2] = sc * v[2]; tile[i][4 * vx + 3] = sc * v[3];
+    }
+    __syncthreads();
+    const int r = r0 + 4 * vx;
+    if (r < j.rows)
+      for (int i = vy; i < 64 && c0 + i < j.cols; i += 16) {
+        u32x2 o;
+        o[0] = (unsigned)bd_f32_to_bf16(tile[4 * vx + 0][i]) | ((unsigned)bd_f32_to_bf16(tile[4 * vx + 1][i]) << 16);
+        o[1] = (unsigned)bd_f32_to_bf16(tile[4 * vx + 2][i]) | ((unsigned)bd_f32_to_bf16(tile[4 * vx + 3][i]) << 16);
+        *(u32x2*)(dst + (size_t)dcol(c0 + i) * j.ld + drow(r)) = o;
+      }
+    return;
+  }
   if (j.transpose & 2) {        // plain fp32 copy (stacked biases)
     if (c0 + tx < j.cols)
       for (int i = ty; i < 64 && r0 + i < j.rows; i += 4)
