@@ -1442,12 +1442,30 @@ static int layernorm_bwd_impl(const void* dy_bf16, const float* x, const float* 
   int rpw = M / (8 * 320);
   rpw = rpw < 1 ? 1 : (rpw > 16 ? 16 : rpw);
   if (rpw > 1) rpw &= ~1;
+  const int nv = (d / 4 + 63) / 64;
+  if (nv >= 3) {
+    // rows of 768 floats and more: the kernel's registers (and 16 d floats of LDS) leave room for ONE workgroup per CU,
+    // so more workgroups than CUs run in two rounds, each with the fixed costs above: an even number of rows per wave
+    // that fits the rows into one round (5120 x 1152: 27.6 us with 160 workgroups against 33.0 with 320; 2560 x 1536: 20.5
+    // against 25.6)
+    static int ncu = 0;
+    if (!ncu) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    static const int wide_rounds = getenv("BD_LNB_WIDE") ? atoi(getenv("BD_LNB_WIDE")) : 1;
+    if (wide_rounds) {
+      int need = (M + 8 * ncu - 1) / (8 * ncu);
+      need = (need + 1) & ~1;
+      rpw = need < 2 ? 2 : (need > 16 ? 16 : need);
+    }
+  }
   dim3 grid((M + 8 * rpw - 1) / (8 * rpw)), block(512);
   const size_t lds = 16 * (size_t)d * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   const unsigned short* dy = (const unsigned short*)dy_bf16;
   unsigned short* ob = (unsigned short*)dx_bf16;
-  const int nv = (d / 4 + 63) / 64;
   bd_prof_scope prof(stream, (double)M * d * (2.0 + 4.0 + 4.0 + 4.0 + (dx_bf16 ? 2.0 : 0.0)), BD_PROF_LN);
 #define BD_LNB(NV)                                                                                              \
   do {                                                                                                          \
