@@ -424,19 +424,28 @@ __device__ __forceinline__ void g256_stage_ready(int later_stages) {
 }
 
 // T = 32-row operand tiles per wave and side (4: the 256 x 256 tile described above, 2: 128 x 128), NS = ring stages
-template <int EPI, bool DROP, int T, int NS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, T == 4 ? 1 : 2))) void gemm256_kernel(GemmArgs p) {
+// NL > 0: NL more waves (4 or 8, T = 2 only) that do nothing but send the LDS-DMA pieces off. A wave moves one 1-KiB
+// piece per 165 clocks at best, however many it keeps in flight (tools_prof/micro/stream_rate.hip), and the four waves
+// of a 128 x 128 tile need four pieces each per 8 MFMAs = 256 clocks of matrix pipe: as their own loaders they run
+// at a quarter of the MFMA rate. The loader waves take the pieces over (two or one per stage and wave) and meet the
+// multiplying waves at the one barrier per step.
+template <int EPI, bool DROP, int T, int NS, int NL = 0>
+__global__ __launch_bounds__(256 + 64 * NL) __attribute__((amdgpu_waves_per_eu(1, T == 4 ? 1 : 2 + NL / 8))) void gemm256_kernel(GemmArgs p) {
   constexpr int TILE = 64 * T;                 // rows of either operand per workgroup
   constexpr int PART = TILE * 64;              // bytes of one operand's rows in a stage (BK = 32)
   constexpr int STAGE = 2 * PART;
-  constexpr int NP = 2 * T;                    // pieces a wave moves per stage (T weight + T activation)
+  constexpr int PL = NL ? (TILE / 16) / NL : T;  // pieces of either part that a piece-moving wave owns
+  constexpr int NP = 2 * PL;                   // pieces such a wave moves per stage (PL weight + PL activation)
   constexpr int NM = T * T;                    // MFMAs per k16 index and wave
+  static_assert(NL == 0 || (T == 2 && (NL == 4 || NL == 8)), "loader waves: 128 x 128 tile, four or eight of them");
   static_assert((NS & (NS - 1)) == 0 && NS >= 4 && NS <= 8, "ring depth: a power of two, 4 .. 8 (buffer index by mask, vmcnt <= 63)");
   static_assert(NP <= NM, "the operand reads and the pieces of a step are placed one per MFMA");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem256[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = (wave >> 1) & 1, wn = wave & 1;
+  const bool loader = NL > 0 && wave >= 4;     // (wave-uniform)
+  const int ow = NL ? wave - 4 : wave;         // index among the waves that move pieces
   const int kh = lane >> 5, r = lane & 31;
   if (EPI == EPI_AXPBY_BF16 || EPI == EPI_BIAS_BF16) {
     const long long b = blockIdx.y;
@@ -472,10 +481,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, T == 4 ?
   // this k-step) and one 32-bit lane offset per piece number. (The builtin with a per-lane 64-bit pointer makes the
   // compiler emit 64-bit vector adds per piece: 57 cycles of issue per piece instead of 20, on a wave whose SIMD has
   // no other wave to run.)
-  unsigned voffw[T], voffa[T];
+  unsigned voffw[PL], voffa[PL];
 #pragma unroll
-  for (int t = 0; t < T; ++t) {
-    const int row = 16 * (T * wave + t) + (lane >> 2);         // 0 .. TILE - 1 inside the part
+  for (int t = 0; t < PL; ++t) {
+    const int row = (16 * (PL * ow + t) + (lane >> 2)) & (TILE - 1);   // 0 .. TILE - 1 inside the part
     const int rho = row & 31, tl = row >> 5;
     const int chunk = (lane & 3) ^ ((rho >> 2) & 3);
     const int np = 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3);
@@ -490,15 +499,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, T == 4 ?
   }
   const unsigned char* const wtile = (const unsigned char*)(p.W + (size_t)n0 * K);
   const unsigned char* const atile = (const unsigned char*)(p.A + (size_t)m0 * K);
-  const unsigned ldsw = (unsigned)(size_t)(g256_lds*)smem256 + wave * (T * 1024);
-  // piece i of stage s: i < T weight rows, else activation rows
+  const unsigned ldsw = (unsigned)(size_t)(g256_lds*)smem256 + (ow & (TILE / 16 / PL - 1)) * (PL * 1024);
+  // piece i of stage s: i < PL weight rows, else activation rows
   auto piece = [&](int s, int i) {
     const unsigned st = ldsw + (s & (NS - 1)) * STAGE;
-    const unsigned char* src = (i < T ? wtile : atile) + (size_t)s * 64;
+    const unsigned char* src = (i < PL ? wtile : atile) + (size_t)s * 64;
     asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"
-                 ::"s"(st), "i"((i % T) * 1024 + (i < T ? 0 : PART)), "v"(i < T ? voffw[i % T] : voffa[i % T]), "s"(src)
+                 ::"s"(st), "i"((i % PL) * 1024 + (i < PL ? 0 : PART)), "v"(i < PL ? voffw[i % PL] : voffa[i % PL]), "s"(src)
                  : "memory", "m0", "scc");
   };
+  if (loader) {
+    // the loader waves' whole life: the ring's stages sent off one per step, each wait and barrier where the
+    // multiplying waves have theirs
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st)
+      if (st < nk) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) piece(st, i);
+      }
+    g256_stage_ready<NP, NS - 2>(min(nk - 1, NS - 2));
+    for (int s = 0; s < nk; ++s) {
+      const bool next = s + 1 < nk, issue = s + NS - 1 < nk;
+      if (next) g256_stage_ready<NP, NS - 3>(min(nk - 2 - s, NS - 3));
+      if (issue) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) piece(s + NS - 1, i);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
 
   f32x16 acc[T][T];
 #pragma unroll
@@ -537,13 +567,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, T == 4 ?
   };
 
   // prologue: stages 0 .. NS - 2 on their way; stage 0 landed; its first operands read
+  if (NL == 0) {
 #pragma unroll
-  for (int st = 0; st < NS - 1; ++st)
-    if (st < nk) {
+    for (int st = 0; st < NS - 1; ++st)
+      if (st < nk) {
 #pragma unroll
-      for (int i = 0; i < NP; ++i) piece(st, i);
-    }
-  g256_stage_ready<NP, NS - 2>(min(nk - 1, NS - 2));
+        for (int i = 0; i < NP; ++i) piece(st, i);
+      }
+    g256_stage_ready<NP, NS - 2>(min(nk - 1, NS - 2));
+  } else {
+    __builtin_amdgcn_s_barrier();              // the loaders' stage 0 has landed
+  }
 #pragma unroll
   for (int i = 0; i < 2 * T; ++i) read1(0, 0, i);
 
@@ -564,7 +598,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, T == 4 ?
         __builtin_amdgcn_sched_barrier(0);
       }
     const bool next = s + 1 < nk, issue = s + NS - 1 < nk;
-    if (next) g256_stage_ready<NP, NS - 3>(min(nk - 2 - s, NS - 3));      // younger stages may still be in flight
+    if (next) {
+      if (NL == 0) g256_stage_ready<NP, NS - 3>(min(nk - 2 - s, NS - 3));      // younger stages may still be in flight
+      else __builtin_amdgcn_s_barrier();
+    }
     wait_reads(1);
 #pragma unroll
     for (int jn = 0; jn < T; ++jn)
@@ -573,7 +610,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, T == 4 ?
         const int i = T * jn + jm;
         acc[jn][jm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[1][jn], fa[1][jm], acc[jn][jm], 0, 0, 0);
         if (i < 2 * T && next) read1(s + 1, 0, i);
-        if (i >= NM - NP && issue) piece(s + NS - 1, i - (NM - NP));
+        if (NL == 0 && i >= NM - NP && issue) piece(s + NS - 1, i - (NM - NP));
         __builtin_amdgcn_sched_barrier(0);
       }
   }
@@ -1019,9 +1056,22 @@ int launch(const GemmArgs& a, hipStream_t s) {
     BD_SET_MAX_LDS((gemm256_kernel<EPI, DROP, 4, 4>), 4 * G256_STAGE);
     hipLaunchKernelGGL((gemm256_kernel<EPI, DROP, 4, 4>), dim3((unsigned)nt), dim3(256), 4 * G256_STAGE, s, a);
   } else if (use_gemm128_ring(a)) {
-    BD_SET_MAX_LDS((gemm256_kernel<EPI, DROP, 2, G128_STAGES>), G128_STAGES * G128_STAGE);
-    hipLaunchKernelGGL((gemm256_kernel<EPI, DROP, 2, G128_STAGES>), dim3((unsigned)a.n_tiles), dim3(256),
-                       G128_STAGES * G128_STAGE, s, a);
+    // four loader waves: 15-22 % faster than the four multiplying waves loading for themselves (N = 384, K = 1536 over
+    // 10 240 rows: 19.8 against 24.2 us; N = 1536, K = 6144 over 2560 rows: 63 against 74); eight are no faster
+    static int loaders = getenv("BD_GEMM_LOADERS") ? atoi(getenv("BD_GEMM_LOADERS")) : 4;
+    if (loaders == 8) {
+      BD_SET_MAX_LDS((gemm256_kernel<EPI, DROP, 2, G128_STAGES, 8>), G128_STAGES * G128_STAGE);
+      hipLaunchKernelGGL((gemm256_kernel<EPI, DROP, 2, G128_STAGES, 8>), dim3((unsigned)a.n_tiles), dim3(768),
+                         G128_STAGES * G128_STAGE, s, a);
+    } else if (loaders == 4) {
+      BD_SET_MAX_LDS((gemm256_kernel<EPI, DROP, 2, G128_STAGES, 4>), G128_STAGES * G128_STAGE);
+      hipLaunchKernelGGL((gemm256_kernel<EPI, DROP, 2, G128_STAGES, 4>), dim3((unsigned)a.n_tiles), dim3(512),
+                         G128_STAGES * G128_STAGE, s, a);
+    } else {
+      BD_SET_MAX_LDS((gemm256_kernel<EPI, DROP, 2, G128_STAGES>), G128_STAGES * G128_STAGE);
+      hipLaunchKernelGGL((gemm256_kernel<EPI, DROP, 2, G128_STAGES>), dim3((unsigned)a.n_tiles), dim3(256),
+                         G128_STAGES * G128_STAGE, s, a);
+    }
   } else {
     hipLaunchKernelGGL((gemm_bf16_kernel<EPI, DROP>), dim3(persistent_grid(a.n_tiles)), dim3(256), 0, s, a);
   }
