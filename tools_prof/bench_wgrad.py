@@ -19,10 +19,12 @@ def bench(M, N, K, ldy=None, iters=30):
     assert rc == 0
     ms = e0.elapsed_time(e1) / iters
     print(f"wgrad M={M} N={N} K={K} ldy={ldy}: {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:8.1f} TF/s", flush=True)
-M = 256 * 128
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 256 * 128
 bench(M, 384, 384)
 bench(M, 384, 384, 1152)
 bench(M, 1152, 384)
 bench(M, 1536, 384)
 bench(M, 384, 1536)
 bench(M, 896, 384)
+bench(M, 1536, 6144)
+bench(M, 4608, 1536)
