@@ -1035,12 +1035,14 @@ bool use_gemm8p(const GemmArgs& a) {
   const long long tiles = (((long long)a.M + 255) / 256) * ((a.Npad + 255) / 256);
   return wide && a.K >= 384 && a.Npad >= 1536 && a.Npad % 256 == 0 && tiles >= 192;
 }
-// the deep-ring 128 x 128 kernel: a long K on at most one tile per CU (3-7 % there, 20-40 % slower beyond)
+// the deep-ring 128 x 128 kernel: at most one tile per CU (ahead there, 20-40 % slower beyond)
 bool use_gemm128_ring(const GemmArgs& a) {
   static int mode = getenv("BD_GEMM128_RING") ? atoi(getenv("BD_GEMM128_RING")) : 1;
   if (!mode || a.n_real != a.Npad || a.K % 32 != 0) return false;
   if (mode == 2) return true;         // every shape (measurements)
-  return a.K >= 1024 && a.n_tiles <= 256;       // one workgroup per CU: with more tiles than CUs the two-per-CU kernel wins
+  // one workgroup per CU: with more tiles than CUs the two-per-CU kernel wins. With its loader waves the ring kernel is
+  // ahead from K = 384 on (10 240 x 384 x 384: 9.0 against 9.6 us, K = 768: 12.6 against 14.6)
+  return a.K >= 384 && a.n_tiles <= 256;
 }
 
 template <int EPI, bool DROP = false>
