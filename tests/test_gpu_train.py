@@ -106,7 +106,9 @@ def test_wgrad_and_colsum(gpu_device, M, N, K):
 
 @pytest.mark.parametrize("M,seg,nseg,K,extra", [(4096, 384, 3, 384, 0), (32768, 384, 3, 384, 0), (32768, 1536, 1, 384, 0),
                                                  (640, 128, 2, 1536, 64), (96, 256, 3, 128, 0), (70, 128, 3, 256, 8),
-                                                 (32, 128, 1, 128, 0)])
+                                                 (32, 128, 1, 128, 0),
+                                                 # large outputs over few tokens (the wide models): one workgroup per tile
+                                                 (2560, 1536, 3, 1536, 0), (1024, 6144, 1, 1536, 0), (608, 1536, 1, 6144, 128)])
 def test_wgrad_segments_with_fused_bias_sums(gpu_device, M, seg, nseg, K, extra):
     """One launch for up to three row segments with separate destinations plus the bias gradients;
     token counts that are multiples of 32 take the LDS-DMA kernel, others the register-staged one;
@@ -143,10 +145,11 @@ def test_wgrad_segments_with_fused_bias_sums(gpu_device, M, seg, nseg, K, extra)
         assert rel(dW2[i], ref[i * seg:(i + 1) * seg]) < 1e-5
 
 
-@pytest.mark.parametrize("M", [200, 256])
-def test_wgrad_exact_integers(gpu_device, M):
+@pytest.mark.parametrize("M,N,K", [(200, 256, 128), (256, 256, 128), (1600, 2048, 1536)])
+def test_wgrad_exact_integers(gpu_device, M, N, K):
+    """Small integers: every fp32 sum is exact, whatever the order of the atomics (the last shape takes the launch
+    with one workgroup per output tile)."""
     dev = gpu_device
-    N, K = 256, 128
     g = torch.Generator().manual_seed(0)
     dY = torch.randint(-3, 4, (M, N), generator=g).float()
     X = torch.randint(-3, 4, (M, K), generator=g).float()
