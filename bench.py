@@ -707,6 +707,9 @@ def main():
                                    f"{args.steps} batches between device synchronisations; kernel durations from HIP events",
                        "batch_per_gpu": B, "seq_len": L, "diffusion_steps": T, "sharding": f"{world} x independent batches"},
             "roofline": roofline_of(table, traffic, traffic_src),
+            # (the contract's objects and a short summary first, the long per-kernel tables behind them)
+            "cpu_baseline": None,
+            "summary": None,
             "kernels": named(table),
             # reference-forward flops per generated sequence / time: a throughput equivalent in the work the
             # reference's loop does (it computes every row of every layer at every step), not matrix-core utilisation
@@ -719,6 +722,24 @@ def main():
             out["configs"] = configs
         if args.cpu_seqs > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(sd_cpu, cfg, smp, L, T, args.cpu_seqs, threads)
+        else:
+            del out["cpu_baseline"]
+        summ = {"sequences_per_s": value, "dominant_kernel_frac": out["roofline"].get("frac")}
+        if isinstance(control, dict) and "zero_weights" in control:
+            summ["zero_operand_control_frac"] = control["zero_weights"].get("frac_of_peak")
+        if isinstance(train, dict) and "ms_per_step" in train:
+            summ["train_ms_per_step"] = train["ms_per_step"]
+            summ["train_tokens_per_s"] = train["value"]
+            summ["train_frac"] = train["roofline"]["frac"]
+        if isinstance(configs, dict):
+            c5 = configs.get("c5_24L_d1024_L512")
+            if isinstance(c5, dict) and "whole_path_frac" in c5:
+                summ["c5_sequences_per_s"] = c5["value"]
+                summ["c5_whole_path_frac"] = c5["whole_path_frac"]
+            ms = configs.get("model_sizes_forward")
+            if isinstance(ms, dict) and "xl" in ms:
+                summ["model_sizes_forward_frac"] = {k: v["whole_path_frac"] for k, v in ms.items() if isinstance(v, dict) and "whole_path_frac" in v}
+        out["summary"] = summ
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
