@@ -1042,7 +1042,8 @@ bool use_gemm128_ring(const GemmArgs& a) {
   if (mode == 2) return true;         // every shape (measurements)
   // one workgroup per CU: with more tiles than CUs the two-per-CU kernel wins. With its loader waves the ring kernel is
   // ahead from K = 384 on (10 240 x 384 x 384: 9.0 against 9.6 us, K = 768: 12.6 against 14.6)
-  return a.K >= 384 && a.n_tiles <= 256;
+  static int min_k = getenv("BD_GEMM128_RING_MINK") ? atoi(getenv("BD_GEMM128_RING_MINK")) : 384;
+  return a.K >= min_k && a.n_tiles <= 256;
 }
 
 template <int EPI, bool DROP = false>
